@@ -1,0 +1,241 @@
+/*
+ * paged_evict.h — C ABI of libpaged_evict.so: MI355X (gfx950) kernels for the
+ * paged-KV-eviction attention path of vllm-Paged-Compression.
+ *
+ * Conventions
+ *  - every pointer named *_dev / documented "device" is a device (HBM) pointer owned
+ *    by the caller; the library never allocates or frees memory in these calls;
+ *  - `stream` is a hipStream_t (NULL = the null stream); all work is enqueued on it
+ *    and the call returns without synchronising;
+ *  - return value: PE_OK (0) or a PE_ERR_* code; pe_last_error() then returns a
+ *    thread-local message.  The Python side turns a non-zero status into
+ *    RuntimeError, mirroring TORCH_CHECK in the reference's ops;
+ *  - `dtype` is a pe_dtype; K/V cache element type == query/key/value element type
+ *    (kv_cache_dtype "auto"; the reference backend rejects fp8 KV,
+ *    vllm/attention/backends/torch_cuda_sdpa.py:769-772);
+ *  - paged cache layouts are the reference's (vllm/attention/ops/paged_attn.py:40-62,
+ *    csrc/cache_kernels.cu:184-191):
+ *        key_cache   [num_blocks, num_kv_heads, head_size/x, block_size, x], x = 16/sizeof(T)
+ *        value_cache [num_blocks, num_kv_heads, head_size, block_size]
+ *
+ * Reference citations are relative to the reference checkout.
+ */
+#ifndef PAGED_EVICT_H_
+#define PAGED_EVICT_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { PE_F32 = 0, PE_F16 = 1, PE_BF16 = 2 } pe_dtype;
+
+enum {
+  PE_OK = 0,
+  PE_ERR_INVALID_ARG = 1, /* shape / pointer / range check failed               */
+  PE_ERR_UNSUPPORTED = 2, /* valid request the kernels do not implement         */
+  PE_ERR_LAUNCH = 3,      /* HIP reported an error at launch                    */
+  PE_ERR_WORKSPACE = 4    /* caller's workspace is too small                    */
+};
+
+/* eviction methods of PagedEvictConfig.evict_method (vllm/config.py:933-991,
+ * vllm/engine/arg_utils.py:971-1036) */
+typedef enum {
+  PE_EVICT_STREAMING = 0,    /* "streamingLLM"   */
+  PE_EVICT_STREAMING_1 = 1,  /* "streamingLLM-1" */
+  PE_EVICT_LOCAL = 2,        /* "local"          */
+  PE_EVICT_GLOBAL = 3,       /* "global"         */
+  PE_EVICT_INVERSE_KEY_L2 = 4 /* "inverse_key_l2" */
+} pe_evict_method;
+
+/* value layouts accepted by pe_block_score_value_l2 */
+typedef enum {
+  PE_SCORE_TOKEN_MAJOR = 0, /* dense [block_size, num_kv_heads, head_size] per block */
+  PE_SCORE_CACHE = 1,       /* paged value cache block, logical V[token, head, :]   */
+  PE_SCORE_CACHE_FLAT = 2   /* paged block re-viewed flat as [-1, heads, head_size],
+                               the reference's decode-time view (quirk)             */
+} pe_score_layout;
+
+const char* pe_last_error(void);
+int pe_version(void);
+
+/* ------------------------------------------------------------------------------------
+ * KV write.  Replaces torch.ops._C_cache_ops.reshape_and_cache
+ * (csrc/torch_bindings.cpp:444-450, kernel csrc/cache_kernels.cu:152-204,263-289;
+ * caller vllm/attention/ops/paged_attn.py:65-84).
+ *   key/value      device [num_tokens, num_kv_heads, head_size], token stride given in
+ *                  elements (head and element strides are dense)
+ *   slot_mapping   device int64[num_tokens]; slot < 0 = padding, skipped
+ *   src_index      optional device int32: row of key/value to read for output token i.
+ *                  NULL: row i.  src_index_head_stride == 0: one row per token
+ *                  (src_index[i]); == 1: one row per (token, head)
+ *                  (src_index[i*num_kv_heads + h]) — the prompt-prune gather fused into
+ *                  the write (replaces the prune_prompt_inplace + reshape_and_cache pair,
+ *                  vllm/attention/backends/torch_cuda_sdpa.py:888-892,1020-1024)
+ *   zero_slots     optional device int64[num_zero_slots]: slots whose K and V rows are
+ *                  set to zero after the write (negative entries skipped).  Replaces the
+ *                  zero rows the reference appends from TmpCacheSingleton
+ *                  (torch_cuda_sdpa.py:919-933,962-976; vllm/worker/tmp_cache_singleton.py)
+ *   num_blocks     blocks in the cache, for the range check of slots (a slot beyond the
+ *                  cache is skipped and counted in *bad_slots_dev if that is non-NULL)
+ * ---------------------------------------------------------------------------------- */
+int pe_reshape_and_cache(const void* key, const void* value, void* key_cache,
+                         void* value_cache, const int64_t* slot_mapping,
+                         int64_t num_tokens, int64_t key_stride, int64_t value_stride,
+                         const int32_t* src_index, int src_index_head_stride,
+                         const int64_t* zero_slots, int64_t num_zero_slots,
+                         int num_kv_heads, int head_size, int block_size,
+                         int64_t num_blocks, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Decode attention over the surviving blocks.  Replaces torch.ops._C.paged_attention_v1
+ * and paged_attention_v2 + reduce (csrc/torch_bindings.cpp:27-51,
+ * csrc/attention/attention_kernels.cuh:86-669; dispatch heuristic
+ * vllm/attention/ops/paged_attn.py:87-191) for the non-fp8, non-block-sparse arms.
+ *   out            device [num_seqs, num_heads, head_size] (dense)
+ *   query          device [num_seqs, num_heads, head_size], seq stride q_stride (elements)
+ *   block_tables   device int32[num_seqs, max_num_blocks_per_seq]
+ *   seq_lens       device int32[num_seqs]: KV length per sequence (seq_kv_lens_tensor
+ *                  under eviction, torch_cuda_sdpa.py:1044-1045)
+ *   alibi_slopes   optional device float[num_heads]
+ *   max_seq_len    upper bound of seq_lens (sizes the split-KV partition count only)
+ *   workspace      device scratch of at least pe_paged_decode_workspace_bytes(...) bytes;
+ *                  may be NULL when that function returns 0
+ * softmax follows the CUDA kernel: p = exp(l - max) / (sum + 1e-6) (:342).
+ * ---------------------------------------------------------------------------------- */
+int64_t pe_paged_decode_workspace_bytes(int num_seqs, int num_heads, int num_kv_heads,
+                                        int head_size, int block_size, int max_seq_len);
+int pe_paged_decode(void* out, const void* query, const void* key_cache,
+                    const void* value_cache, const int32_t* block_tables,
+                    const int32_t* seq_lens, const float* alibi_slopes, int num_seqs,
+                    int num_heads, int num_kv_heads, int head_size, int block_size,
+                    int max_num_blocks_per_seq, int64_t q_stride, int64_t kv_block_stride,
+                    int64_t kv_head_stride, float scale, int max_seq_len, int dtype,
+                    void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Prefill attention.  Replaces TorchCUDASDPABackendImpl._run_sdpa_forward
+ * (vllm/attention/backends/torch_cuda_sdpa.py:1069-1127): per request causal attention
+ * of q[Lq] over k/v[Lkv] with grouped KV heads (no repeat_interleave copy) and the
+ * mask alignment of scaled_dot_product_attention(is_causal=True): query i attends kv
+ * rows 0..min(i, Lkv-1) (top-left aligned when Lq != Lkv, i.e. when the prompt was
+ * pruned before attention).
+ *   q [total_q, num_heads, head_size], k/v [total_kv, num_kv_heads, head_size], token
+ *   strides in elements; cu_q / cu_kv device int32[num_seqs+1] prefix sums;
+ *   max_q_len = longest query (sizes the grid).
+ * ---------------------------------------------------------------------------------- */
+int pe_prefill_causal(void* out, const void* q, const void* k, const void* v,
+                      const int32_t* cu_q, const int32_t* cu_kv, int num_seqs,
+                      int max_q_len, int num_heads, int num_kv_heads, int head_size,
+                      int64_t q_stride, int64_t k_stride, int64_t v_stride,
+                      int64_t out_stride, float scale, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Prompt prune, dense form.  Replaces KVCachePruner.prune_prompt_inplace
+ * (vllm/attention/kvcache_prunner.py:167-281) driven per request by
+ * _prune_prompts_keys_and_values_new (torch_cuda_sdpa.py:1222-1296): gathers the kept
+ * rows of key/value into out_key/out_value [n_out, num_kv_heads, head_size] (dense).
+ * src_index as in pe_reshape_and_cache.
+ * ---------------------------------------------------------------------------------- */
+int pe_prompt_prune_gather(const void* key, const void* value, void* out_key,
+                           void* out_value, const int32_t* src_index,
+                           int src_index_head_stride, int64_t n_out, int64_t key_stride,
+                           int64_t value_stride, int num_kv_heads, int head_size,
+                           int dtype, void* stream);
+
+/* Kept-row index of the streamingLLM prompt prune for a batch of prompts
+ * (kvcache_prunner.py:183-218): for request r with query rows [cu_q[r], cu_q[r+1]) and
+ * kept rows [cu_kept[r], cu_kept[r+1]) writes src_index[cu_kept[r] + n] = absolute row
+ * of the n-th kept token.  cu_q/cu_kept device int32[num_seqs+1]. */
+int pe_prompt_keep_index_streaming(int32_t* src_index, const int32_t* cu_q,
+                                   const int32_t* cu_kept, int num_seqs, int cache_budget,
+                                   int block_size, void* stream);
+
+/* Token-level prompt prune for "local"/"global" (score = ||V||_2) and "inverse_key_l2"
+ * (score = 1/(||K||_2+1e-8)) (kvcache_prunner.py:29-49,220-257): per request and per KV
+ * head drops the n_prune lowest-score middle tokens and writes the per-(token, head)
+ * kept-row index src_index[(cu_kept[r]+n)*num_kv_heads + h].  Scores are rounded to the
+ * storage type like torch.norm's result; equal scores are dropped lowest token first.
+ * compat_q2 != 0 lays the index out the way the reference's `middle[mask].view(-1,H,D)`
+ * re-packs rows across heads (kvcache_prunner.py:251-252); then each entry is
+ * row*num_kv_heads + head of the source (token, head) pair.
+ * workspace: pe_prompt_token_select_workspace_bytes(total_q, num_kv_heads) bytes. */
+int64_t pe_prompt_token_select_workspace_bytes(int64_t total_q, int num_kv_heads);
+int pe_prompt_token_select(int32_t* src_index, const void* key, const void* value,
+                           const int32_t* cu_q, const int32_t* cu_kept, int num_seqs,
+                           int cache_budget, int block_size, int method, int compat_q2,
+                           int64_t key_stride, int64_t value_stride, int num_kv_heads,
+                           int head_size, int dtype, void* workspace,
+                           int64_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Per-block value_l2 score.  Replaces KVCachePruner.get_block_score
+ * (kvcache_prunner.py:51-56): norm over head_size, mean over heads, sum over the
+ * block's tokens, each reduction rounded to the storage type as torch does.
+ *   layout PE_SCORE_TOKEN_MAJOR: values = dense [*, num_kv_heads, head_size]; block i
+ *     covers rows [block_ids[i]*block_size, +block_size) (block_ids NULL: block i = i)
+ *     — the prompt-time call site torch_cuda_sdpa.py:1278-1288;
+ *   layout PE_SCORE_CACHE / PE_SCORE_CACHE_FLAT: values = paged value cache, block i =
+ *     physical block block_ids[i] — the decode-time call site torch_cuda_sdpa.py:1518-1526.
+ *   scores_out device float[n_blocks].
+ * ---------------------------------------------------------------------------------- */
+int pe_block_score_value_l2(float* scores_out, const void* values,
+                            const int32_t* block_ids, int n_blocks, int layout,
+                            int64_t block_stride, int num_kv_heads, int head_size,
+                            int block_size, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Decode-step eviction decision + block-table compaction, one launch per step.
+ * Replaces _prune_decode_reqs_streamingLLM / _prune_decode_reqs_topk /
+ * _create_updated_block_tables (torch_cuda_sdpa.py:1375-1433,1478-1586) and the score
+ * bookkeeping of BlockL2NormManager (vllm/attention/block_l2norm_manager.py:64-75).
+ *
+ * For sequence b with logical length seq_lens[b] (trigger: seq_len > cache_budget and
+ * seq_len % block_size == 0, :1390-1403,1491-1498):
+ *   streamingLLM / streamingLLM-1: victim = block index 1; streamingLLM-1 additionally
+ *     reports, on non-boundary steps past the budget, the slot
+ *     block_tables[b][1]*block_size + seq_len%block_size - 1 in zero_slots_out[b];
+ *   local / global: the just-filled block (table entry num_blocks[b]-1) is scored from the
+ *     value cache, appended to the sequence's score list
+ *     score_table[score_rows[b]][0..score_counts[..]), and the victim is the first
+ *     arg-min over [1, 1+topk_blocks) (local) or [1, n_scores-1) (global).  If
+ *     victim_override is non-NULL and victim_override[b] >= 0 that index is used instead
+ *     (the reference's random mode, :1502-1515, draws it on the host).  With
+ *     drop_victim_score != 0 the victim's entry is deleted from the list so that the
+ *     list keeps tracking the table (the call the reference leaves commented out, :1546).
+ * Outputs: rmv_idx_out[b] = victim index or -1; out_tables[b] = row b without that
+ * column, width max_blocks-1 (intended semantics; compat_q1 != 0 reproduces the
+ * reference's in-loop slice, :1583, and then runs the rows serially);
+ * zero_slots_out[b] = slot to zero or -1 (may be NULL unless streamingLLM-1).
+ * out_tables may be NULL to skip compaction.
+ * ---------------------------------------------------------------------------------- */
+int pe_evict_select_compact(int32_t* rmv_idx_out, int32_t* out_tables,
+                            int64_t* zero_slots_out, const int32_t* block_tables,
+                            const int32_t* seq_lens, const int32_t* num_blocks,
+                            const int32_t* victim_override, int batch, int max_blocks,
+                            int method, int cache_budget, int block_size, int topk_blocks,
+                            int drop_victim_score, int compat_q1, int score_layout,
+                            float* score_table, int32_t* score_counts,
+                            const int32_t* score_rows, int score_table_width,
+                            const void* value_cache, int64_t kv_block_stride,
+                            int num_kv_heads, int head_size, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Block copy / swap — backend-API obligations (vllm/attention/backends/abstract.py:79-94).
+ * pe_copy_blocks replaces torch.ops._C_cache_ops.copy_blocks
+ * (csrc/cache_kernels.cu:68-148): cache_ptrs device arrays of num_layers device pointers,
+ * block_mapping device int64[num_pairs, 2] (src, dst).
+ * pe_swap_blocks replaces swap_blocks (csrc/cache_kernels.cu:24-63): block_mapping is a
+ * HOST int64[num_pairs, 2]; kind 0 = device->device, 1 = device->host, 2 = host->device.
+ * ---------------------------------------------------------------------------------- */
+int pe_copy_blocks(void* const* key_cache_ptrs, void* const* value_cache_ptrs,
+                   const int64_t* block_mapping, int num_layers, int num_pairs,
+                   int64_t numel_per_block, int dtype, void* stream);
+int pe_swap_blocks(const void* src, void* dst, const int64_t* block_mapping_host,
+                   int64_t num_pairs, int64_t block_bytes, int kind, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PAGED_EVICT_H_ */

@@ -1,0 +1,419 @@
+"""TEST INFRASTRUCTURE ONLY — CPU oracle for the paged-KV-eviction attention path.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py`` may import this module; the product package never does.
+
+Two halves:
+
+* ctypes wrappers over ``oracle/libpe_oracle.so`` (``oracle/pe_oracle.c``): KV write,
+  block copy, single-query paged attention, block score, block-table compaction,
+  varlen causal prefill.  Each C function cites the reference lines it restates.
+* small pure-Python / torch-CPU restatements of the integer and index logic of
+  the eviction path (prompt-prune index maps, pruned lengths, decode triggers,
+  victim choice, slot mapping, block-table counters).  Citations are relative to
+  the reference checkout.
+
+Pinning of this oracle against the reference's own code and fixtures is done by
+``tests/test_oracle_golden.py`` (golden vectors made by importing the reference's
+``KVCachePruner`` / ``BlockL2NormManager``) and ``tests/test_oracle_vs_ref.py``
+(the reference's CPU kernels compiled from its sources into ``oracle/_ref``).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import random
+import subprocess
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libpe_oracle.so")
+_DT = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+
+
+def build(force: bool = False) -> str:
+    """Compile oracle/pe_oracle.c with gcc (a few seconds)."""
+    src = os.path.join(_HERE, "pe_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(src) > os.path.getmtime(_LIB_PATH):
+        subprocess.check_call(
+            ["gcc", "-O2", "-fPIC", "-shared", "-std=c11", "-fno-fast-math", "-ffp-contract=off",
+             "-o", _LIB_PATH, src, "-lm"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = ctypes.CDLL(_LIB_PATH)
+        L.orc_block_score.restype = ctypes.c_float
+        L.orc_bf16_to_f32.restype = ctypes.c_float
+        L.orc_f16_to_f32.restype = ctypes.c_float
+        L.orc_f32_to_bf16.restype = ctypes.c_uint16
+        L.orc_f32_to_f16.restype = ctypes.c_uint16
+        L.orc_f32_to_bf16.argtypes = [ctypes.c_float]
+        L.orc_f32_to_f16.argtypes = [ctypes.c_float]
+        L.orc_bf16_to_f32.argtypes = [ctypes.c_uint16]
+        L.orc_f16_to_f32.argtypes = [ctypes.c_uint16]
+        _lib = L
+    return _lib
+
+
+def _p(t: Optional[torch.Tensor]):
+    if t is None:
+        return ctypes.c_void_p(0)
+    assert t.device.type == "cpu"
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _i64(v):
+    return ctypes.c_int64(int(v))
+
+
+# --------------------------------------------------------------------------- C wrappers
+
+def reshape_and_cache(key, value, key_cache, value_cache, slot_mapping) -> None:
+    """key/value [T, H, D]; key_cache [nb, H, D/x, bs, x]; value_cache [nb, H, D, bs]."""
+    assert key_cache.is_contiguous() and value_cache.is_contiguous()
+    slot_mapping = slot_mapping.to(torch.int64).contiguous()
+    T, H, D = key.shape
+    bs, x = key_cache.shape[3], key_cache.shape[4]
+    lib().orc_reshape_and_cache(
+        _p(key), _p(value), _p(key_cache), _p(value_cache), _p(slot_mapping), _i64(T),
+        _i64(key.stride(0)), _i64(value.stride(0)), ctypes.c_int(H), ctypes.c_int(D),
+        ctypes.c_int(bs), ctypes.c_int(x), ctypes.c_int(_DT[key.dtype]))
+
+
+def copy_blocks(key_cache, value_cache, block_mapping) -> None:
+    block_mapping = block_mapping.to(torch.int64).contiguous()
+    lib().orc_copy_blocks(_p(key_cache), _p(value_cache), _p(block_mapping),
+                          _i64(block_mapping.shape[0]), _i64(key_cache[0].numel()),
+                          ctypes.c_int(_DT[key_cache.dtype]))
+
+
+def paged_attention(query, key_cache, value_cache, block_tables, seq_lens, scale,
+                    alibi_slopes=None) -> torch.Tensor:
+    """query [S, Hq, D] -> out [S, Hq, D] (same dtype)."""
+    S, Hq, D = query.shape
+    nb, Hkv, _, bs, x = key_cache.shape
+    block_tables = block_tables.to(torch.int32).contiguous()
+    seq_lens = seq_lens.to(torch.int32).contiguous()
+    out = torch.zeros((S, Hq, D), dtype=query.dtype)
+    if alibi_slopes is not None:
+        alibi_slopes = alibi_slopes.to(torch.float32).contiguous()
+    lib().orc_paged_attention(
+        _p(out), _p(query), _p(key_cache), _p(value_cache), _p(block_tables), _p(seq_lens),
+        _p(alibi_slopes), ctypes.c_int(S), ctypes.c_int(Hq), ctypes.c_int(Hkv),
+        ctypes.c_int(D), ctypes.c_int(bs), ctypes.c_int(x),
+        ctypes.c_int(block_tables.shape[1]), _i64(query.stride(0)),
+        _i64(key_cache.stride(0)), _i64(key_cache.stride(1)), ctypes.c_float(scale),
+        ctypes.c_int(_DT[query.dtype]))
+    return out
+
+
+def block_score(values: torch.Tensor, block_size: int, num_kv_heads: int, head_size: int,
+                layout: int) -> float:
+    """layout 0: [bs,H,D] token-major; 1: cache block [H,D,bs] logical rows;
+    2: cache block re-viewed as [-1,H,D] the way the reference's decode call site does."""
+    values = values.contiguous()
+    return float(lib().orc_block_score(_p(values), ctypes.c_int(block_size),
+                                       ctypes.c_int(num_kv_heads), ctypes.c_int(head_size),
+                                       ctypes.c_int(layout), ctypes.c_int(_DT[values.dtype])))
+
+
+def compact_block_tables(tables: torch.Tensor, rmv_idx: Sequence[int], compat_q1: bool = False):
+    tables = tables.to(torch.int32).contiguous()
+    B, M = tables.shape
+    rmv = torch.tensor(list(rmv_idx), dtype=torch.int32)
+    out = torch.zeros((B, max(M - 1, 0)), dtype=torch.int32)
+    lib().orc_compact_block_tables(_p(tables), _p(rmv), _p(out), ctypes.c_int(B),
+                                   ctypes.c_int(M), ctypes.c_int(1 if compat_q1 else 0))
+    return out
+
+
+def prefill_attention(query, key, value, q_lens: Sequence[int], kv_lens: Sequence[int], scale):
+    """query [Tq,Hq,D], key/value [Tkv,Hkv,D]; causal, top-left aligned when Lq != Lkv."""
+    query, key, value = query.contiguous(), key.contiguous(), value.contiguous()
+    cu_q = torch.tensor([0] + list(torch.tensor(list(q_lens)).cumsum(0)), dtype=torch.int32)
+    cu_kv = torch.tensor([0] + list(torch.tensor(list(kv_lens)).cumsum(0)), dtype=torch.int32)
+    out = torch.zeros_like(query)
+    lib().orc_prefill_attention(
+        _p(out), _p(query), _p(key), _p(value), _p(cu_q), _p(cu_kv), ctypes.c_int(len(q_lens)),
+        ctypes.c_int(query.shape[1]), ctypes.c_int(key.shape[1]), ctypes.c_int(query.shape[2]),
+        ctypes.c_float(scale), ctypes.c_int(_DT[query.dtype]))
+    return out
+
+
+# --------------------------------------------------------------------------- prompt prune
+
+def prompt_slices(q_len: int, budget: int, block_size: int) -> Tuple[int, int, int]:
+    """(end_first, end_middle, n_prune) of KVCachePruner.prune_prompt,
+    vllm/attention/kvcache_prunner.py:78-96 (identical in :118-135, :185-200)."""
+    rem = q_len % block_size
+    end_first = block_size
+    end_mid = q_len - block_size - rem
+    mid_tokens = end_mid - end_first
+    mid_keep = budget - 2 * block_size
+    n_prune = mid_tokens - mid_keep
+    if n_prune < 0:
+        n_prune = 0
+    return end_first, end_mid, n_prune
+
+
+def pruned_length(seq_len: int, budget: int, block_size: int) -> int:
+    """KVCachePruner.get_pruned_length, kvcache_prunner.py:284-326 (same for every method)."""
+    if seq_len <= budget:
+        return seq_len
+    rem = seq_len % block_size
+    end_mid = seq_len - block_size - rem
+    mid_keep = max(budget - block_size - block_size, 0)
+    return block_size + mid_keep + (seq_len - end_mid)
+
+
+def num_required_blocks_after_prune(q_len: int, budget: int, block_size: int,
+                                    initial_blocks: int = 1) -> Tuple[int, int]:
+    """get_num_required_blocks_after_prune_promt, vllm/core/page_evict_kv_util.py:6-36."""
+    if q_len < budget:
+        return -(-q_len // block_size), q_len
+    rem = q_len % block_size
+    end_first = initial_blocks * block_size
+    end_mid = q_len - block_size - rem
+    mid_keep = max(budget - initial_blocks * block_size - block_size, 0)
+    total = end_first + mid_keep + (q_len - end_mid)
+    return -(-total // block_size), total
+
+
+def streaming_keep_indices(q_len: int, budget: int, block_size: int) -> List[int]:
+    """Kept token positions of the streamingLLM prompt prune, kvcache_prunner.py:76-115."""
+    if q_len <= budget:
+        return list(range(q_len))
+    end_first, end_mid, n_prune = prompt_slices(q_len, budget, block_size)
+    return (list(range(0, end_first)) + list(range(end_first + n_prune, end_mid))
+            + list(range(end_mid, q_len)))
+
+
+def token_scores(keys: torch.Tensor, values: torch.Tensor, method: str) -> torch.Tensor:
+    """KVCachePruner.get_token_score, kvcache_prunner.py:29-49 (sub method value_l2, :13)."""
+    if method in ("global", "local"):
+        return torch.norm(values, p=2, dim=-1)
+    if method == "inverse_key_l2":
+        return torch.div(1, torch.norm(keys, p=2, dim=-1) + 1e-8)
+    raise ValueError(method)
+
+
+def topk_keep_mask(scores: torch.Tensor, n_prune: int) -> torch.Tensor:
+    """[T,H] bool keep-mask: per head drop the n_prune lowest scores
+    (kvcache_prunner.py:141-145).  Ties are broken towards the lower token index
+    (a stable ascending sort); torch.topk leaves the tie order unspecified, so tie
+    cases are outside what the reference pins."""
+    T, H = scores.shape
+    keep = torch.ones((T, H), dtype=torch.bool)
+    if n_prune <= 0:
+        return keep
+    order = torch.sort(scores.float(), dim=0, stable=True).indices  # ascending
+    keep.scatter_(0, order[:n_prune], False)
+    return keep
+
+
+def prompt_prune(keys: torch.Tensor, values: torch.Tensor, method: str, budget: int,
+                 block_size: int, compat_q2: bool = False):
+    """KVCachePruner.prune_prompt, kvcache_prunner.py:69-165.  Returns (keys, values).
+
+    compat_q2=False: per-head compaction (kept tokens of head h stay in head h).
+    compat_q2=True: the reference's ``middle[mask].view(-1, H, D)`` (:148-149), which
+    re-packs kept (token, head) rows in row-major order across heads."""
+    L, H, D = keys.shape
+    if L <= budget:
+        return keys, values
+    if method in ("streamingLLM", "streamingLLM-1"):
+        idx = torch.tensor(streaming_keep_indices(L, budget, block_size), dtype=torch.long)
+        return keys[idx], values[idx]
+    end_first, end_mid, n_prune = prompt_slices(L, budget, block_size)
+    mk, mv = keys[end_first:end_mid], values[end_first:end_mid]
+    if n_prune > 0:
+        keep = topk_keep_mask(token_scores(mk, mv, method), n_prune)
+        if compat_q2:
+            pk, pv = mk[keep].view(-1, H, D), mv[keep].view(-1, H, D)
+        else:
+            n_keep = mk.shape[0] - n_prune
+            pk = torch.empty((n_keep, H, D), dtype=keys.dtype)
+            pv = torch.empty((n_keep, H, D), dtype=keys.dtype)
+            for h in range(H):
+                sel = keep[:, h].nonzero().flatten()
+                pk[:, h] = mk[sel, h]
+                pv[:, h] = mv[sel, h]
+    else:
+        pk, pv = mk, mv
+    return (torch.cat([keys[:end_first], pk, keys[end_mid:]], dim=0),
+            torch.cat([values[:end_first], pv, values[end_mid:]], dim=0))
+
+
+# --------------------------------------------------------------------------- slot mapping
+
+def prompt_slot_mapping(block_table: Sequence[int], query_len: int, block_size: int) -> List[int]:
+    """TorchCUDASDPAMetadataBuilder._compute_slot_mapping, prompt arm,
+    vllm/attention/backends/torch_cuda_sdpa.py:577-589."""
+    out: List[int] = []
+    rem = query_len % block_size
+    if rem == 0:
+        for b in block_table:
+            out.extend(b * block_size + i for i in range(block_size))
+    else:
+        for b in block_table[:-1]:
+            out.extend(b * block_size + i for i in range(block_size))
+        out.extend(block_table[-1] * block_size + i for i in range(rem))
+    return out
+
+
+def decode_slot(block_table: Sequence[int], context_len: int, block_size: int) -> int:
+    """Decode arm of the same function, torch_cuda_sdpa.py:591-598."""
+    return block_table[-1] * block_size + context_len % block_size
+
+
+# --------------------------------------------------------------------------- decode decisions
+
+def decode_trigger(seq_len: int, budget: int, block_size: int) -> bool:
+    """Eviction trigger, torch_cuda_sdpa.py:1390-1403,1491-1498 and
+    vllm/worker/model_runner.py:541."""
+    return seq_len > budget and seq_len % block_size == 0
+
+
+def decode_streaming(seq_lens: Sequence[int], block_tables: Sequence[Sequence[int]], budget: int,
+                     block_size: int, method: str):
+    """_prune_decode_reqs_streamingLLM, torch_cuda_sdpa.py:1375-1433.
+    Returns (rmv_idx per sequence (-1 none), zero-slot ids)."""
+    rmv = [-1] * len(seq_lens)
+    zero_slots: List[int] = []
+    for i, L in enumerate(seq_lens):
+        if L <= budget:
+            continue
+        if L % block_size != 0:
+            if method == "streamingLLM-1":
+                zero_slots.append(block_tables[i][1] * block_size + L % block_size - 1)
+        else:
+            rmv[i] = 1
+    return rmv, zero_slots
+
+
+def argmin_first(scores: Sequence[float], start: int, end: int) -> int:
+    """Arg-min with first-min-wins (strict <), torch_cuda_sdpa.py:1536-1541."""
+    r = start
+    for i in range(start, end):
+        if scores[i] < scores[r]:
+            r = i
+    return r
+
+
+def decode_topk_victim(scores: List[float], new_score: float, method: str, topk_blocks: int,
+                       drop_victim_score: bool) -> int:
+    """Score-based victim of _prune_decode_reqs_topk (random off),
+    torch_cuda_sdpa.py:1517-1544: append the just-filled block's score, then arg-min over
+    [1, 1+topk) (local) or [1, n-1) (global).  ``drop_victim_score`` deletes the
+    victim's entry afterwards (the behaviour of the commented-out call at :1546);
+    False keeps HEAD's behaviour, where the list is never shortened."""
+    scores.append(new_score)
+    if method == "local":
+        s, e = 1, 1 + topk_blocks
+    else:
+        s, e = 1, len(scores) - 1
+    e = min(e, len(scores))
+    v = argmin_first(scores, s, e)
+    if drop_victim_score:
+        del scores[v]
+    return v
+
+
+class RandomVictimStream:
+    """HEAD's random victim choice (enable_random_evict=True, torch_cuda_sdpa.py:802,
+    1502-1515): every layer's impl draws from the *global* ``random`` module, seeded
+    1234 by the last impl constructed (:796); only layer 0's draw is committed
+    (vllm/worker/model_runner.py:1797-1802).  Layer 0 draws first in each step, the
+    other ``num_layers-1`` layers then consume the same number of draws with the same
+    arguments."""
+
+    def __init__(self, num_layers: int, seed: int = 1234):
+        self.rng = random.Random(seed)
+        self.num_layers = num_layers
+
+    def step(self, ranges: Sequence[Tuple[int, int]]) -> List[int]:
+        first = [self.rng.randint(a, b) for a, b in ranges]
+        for _ in range(self.num_layers - 1):
+            for a, b in ranges:
+                self.rng.randint(a, b)
+        return first
+
+
+# --------------------------------------------------------------------------- block-table counters
+
+class BlockTableCounters:
+    """The two counters the fork adds to BlockTable (vllm/core/block/block_table.py:
+    58-66,119-126,188-196,456-466): ``num_full_slots`` (logical tokens) and
+    ``num_cached_slots`` (tokens physically cached), plus the block-id list."""
+
+    def __init__(self, block_size: int, budget: Optional[int]):
+        self.bs = block_size
+        self.budget = budget
+        self.blocks: List[int] = []
+        self.num_full_slots = 0
+        self.num_cached_slots = 0
+        self._next = 0
+        self.freed: List[int] = []
+
+    def _new_block(self) -> int:
+        if self.freed:
+            return self.freed.pop(0)
+        b = self._next
+        self._next += 1
+        return b
+
+    def allocate(self, n_tokens: int) -> None:
+        if self.budget is None:
+            n_blocks, kept = -(-n_tokens // self.bs), n_tokens
+        else:
+            n_blocks, kept = num_required_blocks_after_prune(n_tokens, self.budget, self.bs)
+        self.blocks = [self._new_block() for _ in range(n_blocks)]
+        self.num_full_slots = n_tokens
+        if self.budget is None:
+            self.num_cached_slots = n_tokens
+        else:
+            rem = n_tokens % self.bs
+            self.num_cached_slots = n_blocks * self.bs if rem == 0 else (n_blocks - 1) * self.bs + rem
+
+    def append_token(self) -> None:
+        if len(self.blocks) * self.bs - self.num_cached_slots < 1:
+            self.blocks.append(self._new_block())
+        self.num_full_slots += 1
+        self.num_cached_slots += 1
+
+    def free_pruned_block(self, idx: int) -> None:
+        self.freed.append(self.blocks[idx])
+        self.num_cached_slots -= self.bs
+        del self.blocks[idx]
+
+
+def simulate_streaming_generation(prompt_len: int, out_len: int, budget: int, block_size: int):
+    """Trace of (seq_len, kv_len passed to attention, n_blocks in table passed to
+    attention, rmv_idx) per decode step for the streamingLLM method, composing
+    block_table.py (allocate/append/free), model_runner.py:538-543 and
+    torch_cuda_sdpa.py:1375-1433 + llm_engine.py:1179-1193."""
+    bt = BlockTableCounters(block_size, budget)
+    bt.allocate(prompt_len)
+    trace = []
+    for _ in range(out_len):
+        bt.append_token()
+        seq_len = bt.num_full_slots
+        kv_len = bt.num_cached_slots
+        rmv = -1
+        if decode_trigger(seq_len, budget, block_size):
+            kv_len -= block_size
+            rmv = 1
+        trace.append((seq_len, kv_len, len(bt.blocks) - (1 if rmv >= 0 else 0), rmv))
+        if rmv >= 0:
+            bt.free_pruned_block(rmv)
+    return trace

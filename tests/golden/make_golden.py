@@ -1,0 +1,176 @@
+"""Generates the golden vectors under tests/golden/ by running the *reference's own
+code* in the build container:
+
+* ``vllm/attention/kvcache_prunner.py`` and ``vllm/attention/block_l2norm_manager.py``
+  are loaded straight from the reference checkout (they import only torch/stdlib);
+* the reference's CPU kernels (``csrc/cpu/cache.cpp``, ``csrc/cpu/attention.cpp``)
+  are used through ``oracle/_ref/libpe_ref.so`` (built by ``oracle/build_ref.sh``).
+
+Only data (inputs and expected outputs) is written; no reference source travels.
+Run:  python tests/golden/make_golden.py  [--reference /root/reference]
+"""
+import argparse
+import importlib.util
+import json
+import os
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+
+
+def load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def bits(t: torch.Tensor) -> np.ndarray:
+    """Raw storage of a tensor as a numpy array (bf16/fp16 -> uint16)."""
+    if t.dtype in (torch.bfloat16, torch.float16):
+        return t.contiguous().view(torch.int16).numpy().view(np.uint16).copy()
+    return t.contiguous().numpy().copy()
+
+
+def tagged_kv(L, H, D, dtype):
+    """K/V whose every (token, head) row is identifiable: element 0 = token index,
+    element 1 = head index (exact in bf16 for the sizes used via two-part split)."""
+    k = torch.zeros(L, H, D, dtype=torch.float32)
+    t = torch.arange(L, dtype=torch.float32)
+    k[:, :, 0] = (t // 64)[:, None]
+    k[:, :, 1] = (t % 64)[:, None]
+    k[:, :, 2] = torch.arange(H, dtype=torch.float32)[None, :]
+    return k.to(dtype), (k + 0).to(dtype)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reference", default="/root/reference")
+    args = ap.parse_args()
+    ref = args.reference
+    kp = load("ref_kvcache_prunner", f"{ref}/vllm/attention/kvcache_prunner.py")
+    bm = load("ref_block_l2norm_manager", f"{ref}/vllm/attention/block_l2norm_manager.py")
+
+    # ---- (ii) get_pruned_length table + streamingLLM kept-token maps -------------
+    table = []
+    for bs in (8, 16, 32):
+        for budget in (3 * bs, 4 * bs, 128, 256, 512, 768, 4096):
+            if budget < 3 * bs or budget % bs:
+                continue
+            for method in ("streamingLLM", "streamingLLM-1", "inverse_key_l2", "local", "global"):
+                p = kp.KVCachePruner("budget", method, bs, budget, 1)
+                for L in (1, bs, 3 * bs, budget - 1, budget, budget + 1, budget + bs, budget + bs + 3,
+                          1024, 1030, 2 * budget + 5, 8192):
+                    table.append([bs, budget, method, L, int(p.get_pruned_length(L))])
+    keep = []
+    for (L, budget, bs) in [(80, 48, 16), (100, 48, 16), (1024, 768, 16), (1024, 512, 16),
+                            (1030, 512, 16), (1030, 768, 16), (512, 512, 16), (513, 512, 16),
+                            (200, 96, 32), (77, 24, 8), (64, 48, 16), (70, 48, 16)]:
+        p = kp.KVCachePruner("budget", "streamingLLM", bs, budget, 1)
+        k, v = tagged_kv(L, 2, 8, torch.float32)
+        pk, pv = p.prune_prompt(k, v)
+        src = (pk[:, 0, 0] * 64 + pk[:, 0, 1]).to(torch.int64).tolist()
+        ok = torch.empty(p.get_pruned_length(L), 2, 8)
+        ov = torch.empty_like(ok)
+        p.prune_prompt_inplace(k, v, ok, ov)
+        assert torch.equal(ok, pk) and torch.equal(ov, pv)
+        keep.append({"L": L, "budget": budget, "bs": bs, "kept": src})
+    with open(os.path.join(HERE, "prune_tables.json"), "w") as f:
+        json.dump({"pruned_length": table, "streaming_keep": keep}, f)
+
+    # ---- (i) token-level prompt prune (local/global/inverse_key_l2), tie-free f32 --
+    out = {}
+    case = 0
+    for method in ("global", "local", "inverse_key_l2"):
+        for (L, budget, bs, H, D) in [(80, 48, 16, 4, 16), (100, 48, 16, 2, 16), (150, 64, 16, 3, 8)]:
+            for seed in (0, 1):
+                g = torch.Generator().manual_seed(1000 * case + seed)
+                k = torch.rand(L, H, D, generator=g) * 2 - 1
+                v = torch.rand(L, H, D, generator=g) * 2 - 1
+                p = kp.KVCachePruner("budget", method, bs, budget, 1)
+                pk, pv = p.prune_prompt(k, v)
+                name = f"c{case}"
+                out[name + "_meta"] = np.array([L, budget, bs, H, D, ["global", "local", "inverse_key_l2"].index(method)])
+                out[name + "_k"], out[name + "_v"] = bits(k), bits(v)
+                out[name + "_pk"], out[name + "_pv"] = bits(pk), bits(pv)
+                case += 1
+    np.savez_compressed(os.path.join(HERE, "prompt_prune_topk.npz"), **out)
+
+    # ---- (iii) block scores ---------------------------------------------------------
+    out = {}
+    case = 0
+    p = kp.KVCachePruner("budget", "global", 16, 512, 1)
+    for dtype, H, D, bs in [(torch.bfloat16, 8, 128, 16), (torch.float16, 12, 64, 16),
+                            (torch.float32, 8, 128, 16), (torch.bfloat16, 1, 128, 16),
+                            (torch.bfloat16, 8, 128, 32), (torch.float16, 4, 64, 8)]:
+        for seed in (0, 1, 2):
+            g = torch.Generator().manual_seed(7 + 13 * case)
+            scale = D ** -0.5
+            v = ((torch.rand(bs, H, D, generator=g) * 2 - 1) * scale).to(dtype)
+            s = p.get_block_score(v, v, "global")
+            out[f"c{case}_v"] = bits(v)
+            out[f"c{case}_score"] = bits(s.reshape(1))
+            out[f"c{case}_meta"] = np.array([bs, H, D, {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}[dtype]])
+            case += 1
+    np.savez_compressed(os.path.join(HERE, "block_scores.npz"), **out)
+
+    # ---- (iv) BlockL2NormManager bookkeeping ----------------------------------------
+    mgr = bm.BlockL2NormManager()
+    steps = [
+        {"r0": {0: [1, 2, 3]}, "r1": {1: [4, 5]}},
+        {"r0": {0: [1, 2, 3]}, "r1": {1: [4, 5]}},
+        {"r1": {1: [4, 5, 6]}, "r2": {2: [7]}},
+        {"r2": {2: [7, 8]}, "r3": {3: [9, 10]}, "r1": {1: [4, 5, 6]}},
+    ]
+    log = []
+    for st in steps:
+        mgr.update_reqs(st)
+        log.append({"input": {k: {str(s): b for s, b in v.items()} for k, v in st.items()},
+                    "flat_sequence_map": [[r, s] for r, s in mgr.flat_sequence_map],
+                    "norm_keys": sorted(mgr.reqid_mapping_block_l2norms.keys())})
+    mgr.update_block_l2norms(0, [1.0, 2.0, 3.0])
+    after_append = list(mgr.update_last_block_l2norm(0, 0.5))
+    with open(os.path.join(HERE, "l2norm_manager.json"), "w") as f:
+        json.dump({"steps": log, "after_append": after_append,
+                   "seq0": list(mgr.get_reqid_and_seqid(0))}, f)
+
+    # ---- (vi) reference CPU kernels: KV write + paged attention ----------------------
+    lib = os.path.join(ROOT, "oracle", "_ref", "libpe_ref.so")
+    torch.ops.load_library(lib)
+    out = {}
+    case = 0
+    for dtype, Hq, Hkv, D in [(torch.bfloat16, 8, 2, 64), (torch.float32, 4, 2, 64), (torch.bfloat16, 4, 1, 128)]:
+        g = torch.Generator().manual_seed(100 + case)
+        nb, bs = 12, 16
+        x = 16 // torch.tensor([], dtype=dtype).element_size()
+        scale = D ** -0.5
+        T = nb * bs
+        k = ((torch.rand(T + 1, Hkv, D, generator=g) * 2 - 1) * scale).to(dtype)
+        v = ((torch.rand(T + 1, Hkv, D, generator=g) * 2 - 1) * scale).to(dtype)
+        slots = torch.randperm(nb * bs + 1, generator=g).to(torch.int64)
+        slots[slots == nb * bs] = -1  # one padding token, every real slot written once
+        kc = torch.zeros(nb, Hkv, D // x, bs, x, dtype=dtype)
+        vc = torch.zeros(nb, Hkv, D, bs, dtype=dtype)
+        torch.ops.pe_ref.reshape_and_cache(k, v, kc, vc, slots, "auto", 1.0, 1.0)
+        S = 4
+        q = ((torch.rand(S, Hq, D, generator=g) * 2 - 1) * scale).to(dtype)
+        lens = torch.tensor([1, 16, 37, 90], dtype=torch.int32)
+        M = 6
+        bt = torch.randint(0, nb, (S, M), generator=g, dtype=torch.int32)
+        o = torch.zeros_like(q)
+        torch.ops.pe_ref.paged_attention_v1(o, q, kc, vc, Hkv, scale, bt, lens, bs, 90, None, "auto",
+                                            1.0, 1.0, 0, 0, 0, 64, 0)
+        out[f"c{case}_meta"] = np.array([Hq, Hkv, D, bs, nb, {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}[dtype]])
+        for n, t in [("k", k), ("v", v), ("slots", slots), ("kc_out", kc), ("vc_out", vc), ("q", q),
+                     ("lens", lens), ("bt", bt), ("o", o)]:
+            out[f"c{case}_{n}"] = bits(t)
+        case += 1
+    np.savez_compressed(os.path.join(HERE, "ref_cpu_kernels.npz"), **out)
+    print("golden vectors written to", HERE)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,407 @@
+"""GPU parity tests: the HIP kernels (called through the C ABI via the torch-level ops)
+against the CPU oracle on the same seeded inputs, and against the golden vectors made
+from the reference's own code.  Bit-exact for byte/integer work; floating-point
+tolerances are the ones the reference's kernel tests use."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, from_bits
+
+pytestmark = pytest.mark.gpu
+
+# tolerance of the reference's paged-attention test on ROCm
+# (tests/kernels/test_attention.py:323-331 with tests/kernels/allclose_default.py:5-10)
+ATOL = {torch.bfloat16: 1e-3, torch.float16: 1e-3, torch.float32: 1e-5}
+RTOL = {torch.bfloat16: 1.6e-2, torch.float16: 1e-3, torch.float32: 1.3e-6}
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import vllm_paged_compression_amd.ops as ops
+    import vllm_paged_compression_amd as pkg
+    pkg.load_library()
+    return ops
+
+
+def make_cache(nb, H, D, bs, dtype, g, scale=None):
+    x = 16 // torch.tensor([], dtype=dtype).element_size()
+    scale = D ** -0.5 if scale is None else scale
+    kc = ((torch.rand(nb, H, D // x, bs, x, generator=g) * 2 - 1) * scale).to(dtype)
+    vc = ((torch.rand(nb, H, D, bs, generator=g) * 2 - 1) * scale).to(dtype)
+    return kc, vc
+
+
+# ------------------------------------------------------------------ KV write
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("H,D,bs", [(8, 128, 16), (12, 64, 16), (2, 80, 16), (8, 128, 32), (4, 64, 8)])
+@pytest.mark.parametrize("pattern", ["random", "prefill", "decode"])
+def test_reshape_and_cache(ops, oracle, dtype, H, D, bs, pattern):
+    g = torch.Generator().manual_seed(hash((H, D, bs, pattern)) % 1000)
+    nb = 64
+    if pattern == "random":
+        T = 57
+        slots = torch.randperm(nb * bs, generator=g)[:T].to(torch.int64)
+        slots[7] = -1
+    elif pattern == "prefill":
+        # consecutive slots of whole blocks + a partial last block, as _compute_slot_mapping builds
+        blocks = torch.randperm(nb, generator=g)[:7].tolist()
+        T = 6 * bs + 5
+        slots = torch.tensor(oracle.prompt_slot_mapping(blocks, T, bs), dtype=torch.int64)
+    else:
+        T = 9
+        slots = (torch.randperm(nb, generator=g)[:T] * bs + torch.randint(0, bs, (T,), generator=g)).to(torch.int64)
+    k = (torch.rand(T, H, D, generator=g) - 0.5).to(dtype)
+    v = (torch.rand(T, H, D, generator=g) - 0.5).to(dtype)
+    kc, vc = make_cache(nb, H, D, bs, dtype, g)
+    kc_d, vc_d = kc.cuda(), vc.cuda()
+    oracle.reshape_and_cache(k, v, kc, vc, slots)
+    ops.reshape_and_cache(k.cuda(), v.cuda(), kc_d, vc_d, slots.cuda(), "auto", 1.0, 1.0)
+    torch.cuda.synchronize()
+    assert torch.equal(kc_d.cpu(), kc) and torch.equal(vc_d.cpu(), vc)
+
+
+def test_reshape_and_cache_strided_and_empty(ops, oracle):
+    g = torch.Generator().manual_seed(5)
+    nb, H, D, bs, T = 16, 8, 128, 16, 33
+    # key/value as slices of a fused qkv activation (token stride > H*D)
+    qkv = (torch.rand(T, (32 + 2 * H) * D, generator=g) - 0.5).to(torch.bfloat16)
+    k = qkv[:, 32 * D:(32 + H) * D].view(T, H, D)
+    v = qkv[:, (32 + H) * D:].view(T, H, D)
+    slots = torch.randperm(nb * bs, generator=g)[:T].to(torch.int64)
+    kc, vc = make_cache(nb, H, D, bs, torch.bfloat16, g)
+    kc_d, vc_d = kc.cuda(), vc.cuda()
+    qkv_d = qkv.cuda()
+    kd = qkv_d[:, 32 * D:(32 + H) * D].view(T, H, D)
+    vd = qkv_d[:, (32 + H) * D:].view(T, H, D)
+    oracle.reshape_and_cache(k, v, kc, vc, slots)
+    ops.reshape_and_cache(kd, vd, kc_d, vc_d, slots.cuda())
+    assert torch.equal(kc_d.cpu(), kc) and torch.equal(vc_d.cpu(), vc)
+    # zero tokens: nothing happens
+    ops.reshape_and_cache(kd[:0], vd[:0], kc_d, vc_d, slots[:0].cuda())
+    assert torch.equal(kc_d.cpu(), kc)
+
+
+def test_reshape_and_cache_gather_and_zero(ops, oracle):
+    """Fused prompt-prune gather (streamingLLM keep index) and evicted-slot zeroing."""
+    g = torch.Generator().manual_seed(6)
+    nb, H, D, bs = 80, 8, 128, 16
+    L, budget = 1030, 512
+    k = (torch.rand(L, H, D, generator=g) - 0.5).to(torch.bfloat16)
+    v = (torch.rand(L, H, D, generator=g) - 0.5).to(torch.bfloat16)
+    keep = oracle.streaming_keep_indices(L, budget, bs)
+    n_blocks, n_tok = oracle.num_required_blocks_after_prune(L, budget, bs)
+    assert len(keep) == n_tok
+    blocks = torch.randperm(nb, generator=g)[:n_blocks].tolist()
+    slots = torch.tensor(oracle.prompt_slot_mapping(blocks, L, bs), dtype=torch.int64)
+    assert slots.numel() == n_tok
+    kc, vc = make_cache(nb, H, D, bs, torch.bfloat16, g)
+    kc_d, vc_d = kc.cuda(), vc.cuda()
+    pk, pv = oracle.prompt_prune(k, v, "streamingLLM", budget, bs)
+    oracle.reshape_and_cache(pk, pv, kc, vc, slots)
+    zero = torch.tensor([blocks[1] * bs + 3, -1, blocks[2] * bs + 15], dtype=torch.int64)
+    zk = torch.zeros(3, H, D, dtype=torch.bfloat16)
+    oracle.reshape_and_cache(zk, zk, kc, vc, zero)
+    cu_q = torch.tensor([0, L], dtype=torch.int32).cuda()
+    cu_kept = torch.tensor([0, n_tok], dtype=torch.int32).cuda()
+    idx = ops.prompt_keep_index_streaming(cu_q, cu_kept, n_tok, budget, bs)
+    assert idx.cpu().tolist() == keep
+    ops.reshape_and_cache(k.cuda(), v.cuda(), kc_d, vc_d, slots.cuda(), src_index=idx,
+                          zero_slots=zero.cuda())
+    assert torch.equal(kc_d.cpu(), kc) and torch.equal(vc_d.cpu(), vc)
+    # dense form of the same gather
+    dk, dv = ops.prompt_prune_gather(k.cuda(), v.cuda(), idx)
+    assert torch.equal(dk.cpu(), pk) and torch.equal(dv.cpu(), pv)
+
+
+def test_keep_index_streaming_batch(ops, oracle):
+    bs, budget = 16, 96
+    lens = [40, 96, 97, 200, 333, 112]
+    kept = [oracle.pruned_length(L, budget, bs) for L in lens]
+    cu_q = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32)
+    cu_k = torch.tensor([0] + list(np.cumsum(kept)), dtype=torch.int32)
+    idx = ops.prompt_keep_index_streaming(cu_q.cuda(), cu_k.cuda(), int(cu_k[-1]), budget, bs).cpu().tolist()
+    expect = []
+    for r, L in enumerate(lens):
+        expect += [int(cu_q[r]) + i for i in oracle.streaming_keep_indices(L, budget, bs)]
+    assert idx == expect
+
+
+def test_golden_ref_cpu_kernels(ops):
+    """KV write exact, decode attention within tolerance of the reference's CPU kernels."""
+    z = np.load(os.path.join(GOLDEN, "ref_cpu_kernels.npz"))
+    n = len([k for k in z.files if k.endswith("_meta")])
+    for c in range(n):
+        Hq, Hkv, D, bs, nb, dt = [int(v) for v in z[f"c{c}_meta"]]
+        x = 16 // (4 if dt == 0 else 2)
+        k, v = from_bits(z[f"c{c}_k"], dt), from_bits(z[f"c{c}_v"], dt)
+        kc = torch.zeros(nb, Hkv, D // x, bs, x, dtype=k.dtype, device="cuda")
+        vc = torch.zeros(nb, Hkv, D, bs, dtype=k.dtype, device="cuda")
+        ops.reshape_and_cache(k.cuda(), v.cuda(), kc, vc, torch.from_numpy(z[f"c{c}_slots"]).cuda())
+        assert torch.equal(kc.cpu(), from_bits(z[f"c{c}_kc_out"], dt))
+        assert torch.equal(vc.cpu(), from_bits(z[f"c{c}_vc_out"], dt))
+        q = from_bits(z[f"c{c}_q"], dt).cuda()
+        out = torch.empty_like(q)
+        lens = torch.from_numpy(z[f"c{c}_lens"]).cuda()
+        bt = torch.from_numpy(z[f"c{c}_bt"]).cuda()
+        ops.paged_attention_v1(out, q, kc, vc, Hkv, D ** -0.5, bt, lens, bs, 90, None, "auto", 1.0, 1.0)
+        ref = from_bits(z[f"c{c}_o"], dt)
+        torch.testing.assert_close(out.cpu().float(), ref.float(), atol=1e-3, rtol=1.6e-2)
+
+
+# ------------------------------------------------------------------ decode attention
+DECODE_CASES = [
+    # Hq, Hkv, D, bs, dtype, lens
+    (32, 8, 128, 16, torch.bfloat16, [1, 15, 16, 17, 31, 32, 33, 300, 777, 784]),
+    (32, 8, 128, 16, torch.float16, [768, 769, 783, 784, 5]),
+    (12, 12, 64, 16, torch.float16, [1024, 1100, 1124, 7]),
+    (8, 1, 128, 16, torch.bfloat16, [3072, 100, 3088]),
+    (64, 8, 128, 16, torch.bfloat16, [200, 40]),
+    (16, 1, 256, 16, torch.bfloat16, [130, 33]),
+    (40, 40, 80, 16, torch.bfloat16, [77, 300]),      # generic path (head size)
+    (32, 8, 128, 32, torch.bfloat16, [100, 515]),     # generic path (block size)
+    (8, 2, 64, 8, torch.float16, [9, 130]),           # generic path (block size)
+    (8, 2, 128, 16, torch.float32, [50, 333]),        # generic path (f32)
+    (34, 2, 128, 16, torch.bfloat16, [70, 200]),      # 17 query heads per KV head -> generic
+]
+
+
+@pytest.mark.parametrize("Hq,Hkv,D,bs,dtype,lens", DECODE_CASES)
+@pytest.mark.parametrize("alibi", [False, True])
+def test_paged_decode(ops, oracle, Hq, Hkv, D, bs, dtype, lens, alibi):
+    g = torch.Generator().manual_seed(Hq * 131 + D + len(lens))
+    nb = 300
+    sc = D ** -0.5
+    kc, vc = make_cache(nb, Hkv, D, bs, dtype, g)
+    S = len(lens)
+    q = ((torch.rand(S, Hq, D, generator=g) * 2 - 1) * sc).to(dtype)
+    M = (max(lens) + bs - 1) // bs + 1
+    bt = torch.randint(0, nb, (S, M), generator=g, dtype=torch.int32)
+    lens_t = torch.tensor(lens, dtype=torch.int32)
+    slopes = torch.randn(Hq, generator=g) * 0.1 if alibi else None
+    ref = oracle.paged_attention(q, kc, vc, bt, lens_t, sc, slopes)
+    out = torch.empty_like(q, device="cuda")
+    ops.paged_attention_v1(out, q.cuda(), kc.cuda(), vc.cuda(), Hkv, sc, bt.cuda(), lens_t.cuda(), bs,
+                           max(lens), None if slopes is None else slopes.cuda(), "auto", 1.0, 1.0)
+    torch.testing.assert_close(out.cpu().float(), ref.float(), atol=ATOL[dtype], rtol=RTOL[dtype])
+
+
+@pytest.mark.parametrize("splits", [1, 2, 3, 7])
+def test_paged_decode_split_kv(ops, oracle, splits, monkeypatch):
+    """Forced split counts (the partial-merge path) give the same result."""
+    monkeypatch.setenv("PE_DECODE_SPLITS", str(splits))
+    g = torch.Generator().manual_seed(splits)
+    Hq, Hkv, D, bs, nb = 32, 8, 128, 16, 512
+    lens = [4000, 1, 2049, 33]
+    sc = D ** -0.5
+    kc, vc = make_cache(nb, Hkv, D, bs, torch.bfloat16, g)
+    q = ((torch.rand(len(lens), Hq, D, generator=g) * 2 - 1) * sc).to(torch.bfloat16)
+    M = 4000 // bs
+    bt = torch.randint(0, nb, (len(lens), M), generator=g, dtype=torch.int32)
+    lens_t = torch.tensor(lens, dtype=torch.int32)
+    ref = oracle.paged_attention(q, kc, vc, bt, lens_t, sc)
+    out = torch.empty_like(q, device="cuda")
+    tmp = torch.empty(1, device="cuda")
+    ops.paged_attention_v2(out, tmp, tmp, tmp, q.cuda(), kc.cuda(), vc.cuda(), Hkv, sc, bt.cuda(),
+                           lens_t.cuda(), bs, 4000, None, "auto", 1.0, 1.0)
+    torch.testing.assert_close(out.cpu().float(), ref.float(), atol=1e-3, rtol=1.6e-2)
+
+
+def test_paged_decode_forced_branches(ops, oracle):
+    """Inputs that force the online-softmax rescale: one key far above the rest, placed late,
+    and a sequence whose only large logits sit in the masked tail of the last block."""
+    g = torch.Generator().manual_seed(11)
+    Hq, Hkv, D, bs, nb = 32, 8, 128, 16, 64
+    kc, vc = make_cache(nb, Hkv, D, bs, torch.bfloat16, g)
+    q = ((torch.rand(2, Hq, D, generator=g) * 2 - 1) * 0.3).to(torch.bfloat16)
+    lens = torch.tensor([700, 35], dtype=torch.int32)
+    bt = torch.arange(0, 2 * 44, dtype=torch.int32).reshape(2, 44) % nb
+    # spike: token 650 of sequence 0 aligned with q[0, head 5]
+    blk, off = int(bt[0, 650 // bs]), 650 % bs
+    kc[blk, 1, :, off, :] = (q[0, 5].float() * 40).to(torch.bfloat16).view(D // 8, 8)
+    # garbage (huge) values beyond seq_len in the last block of sequence 1 must be ignored
+    blk1 = int(bt[1, 2])
+    kc[blk1, :, :, 4:, :] = 100.0
+    vc[blk1, :, :, 4:] = float("nan")
+    ref = oracle.paged_attention(q, kc, vc, bt, lens, D ** -0.5)
+    out = torch.empty_like(q, device="cuda")
+    ops.paged_attention_v1(out, q.cuda(), kc.cuda(), vc.cuda(), Hkv, D ** -0.5, bt.cuda(), lens.cuda(),
+                           bs, 700, None, "auto", 1.0, 1.0)
+    assert torch.isfinite(out).all()
+    torch.testing.assert_close(out.cpu().float(), ref.float(), atol=2e-3, rtol=1.6e-2)
+
+
+def test_paged_decode_errors(ops):
+    q = torch.zeros(1, 8, 128, dtype=torch.bfloat16, device="cuda")
+    kc = torch.zeros(4, 2, 16, 16, 8, dtype=torch.bfloat16, device="cuda")
+    vc = torch.zeros(4, 2, 128, 16, dtype=torch.bfloat16, device="cuda")
+    bt = torch.zeros(1, 2, dtype=torch.int32, device="cuda")
+    lens = torch.ones(1, dtype=torch.int32, device="cuda")
+    out = torch.empty_like(q)
+    with pytest.raises(NotImplementedError):
+        ops.paged_attention_v1(out, q, kc, vc, 2, 1.0, bt, lens, 16, 1, None, "fp8", 1.0, 1.0)
+    with pytest.raises(RuntimeError):  # table too narrow for max_seq_len
+        ops.paged_attention_v1(out, q, kc, vc, 2, 1.0, bt, lens, 16, 100, None, "auto", 1.0, 1.0)
+    with pytest.raises(RuntimeError):  # CPU tensors
+        ops.paged_attention_v1(out.cpu(), q.cpu(), kc.cpu(), vc.cpu(), 2, 1.0, bt.cpu(), lens.cpu(), 16, 1,
+                               None, "auto", 1.0, 1.0)
+    with pytest.raises(ValueError):
+        ops.paged_attention_v1(out, q, kc, vc, 2, 1.0, bt, lens, 16, 1, None, "auto", 1.0, 1.0, 0, 2, 4, 64, 0)
+
+
+# ------------------------------------------------------------------ block copy / swap
+def test_copy_and_swap_blocks(ops, oracle):
+    g = torch.Generator().manual_seed(2)
+    layers = 3
+    kcs, vcs = zip(*[make_cache(10, 2, 64, 16, torch.bfloat16, g) for _ in range(layers)])
+    kd, vd = [t.cuda() for t in kcs], [t.cuda() for t in vcs]
+    mapping = torch.tensor([[0, 5], [0, 6], [3, 9]], dtype=torch.int64)
+    for kc, vc in zip(kcs, vcs):
+        oracle.copy_blocks(kc, vc, mapping)
+    ops.copy_blocks(kd, vd, mapping.cuda())
+    for i in range(layers):
+        assert torch.equal(kd[i].cpu(), kcs[i]) and torch.equal(vd[i].cpu(), vcs[i])
+    # swap GPU -> CPU -> GPU round trip
+    src = kd[0]
+    host = torch.zeros_like(kcs[0]).pin_memory()
+    ops.swap_blocks(src, host, torch.tensor([[1, 2], [4, 0]], dtype=torch.int64))
+    torch.cuda.synchronize()
+    assert torch.equal(host[2], kcs[0][1]) and torch.equal(host[0], kcs[0][4])
+    dst = torch.zeros_like(src)
+    ops.swap_blocks(host, dst, torch.tensor([[2, 7]], dtype=torch.int64))
+    torch.cuda.synchronize()
+    assert torch.equal(dst[7].cpu(), kcs[0][1])
+    with pytest.raises(RuntimeError):
+        ops.swap_blocks(src, dst, torch.tensor([[0, 1]], dtype=torch.int64).cuda())
+
+
+# ------------------------------------------------------------------ eviction scoring / decision
+def test_block_score_golden(ops, oracle):
+    z = np.load(os.path.join(GOLDEN, "block_scores.npz"))
+    n = len([k for k in z.files if k.endswith("_meta")])
+    for c in range(n):
+        bs, H, D, dt = [int(v) for v in z[f"c{c}_meta"]]
+        v = from_bits(z[f"c{c}_v"], dt)
+        expect = from_bits(z[f"c{c}_score"], dt).float().item()
+        got = ops.block_score_value_l2(v.cuda(), None, 1, ops.SCORE_TOKEN_MAJOR, H, D, bs).item()
+        vc = v.permute(1, 2, 0).contiguous().cuda()
+        got_c = ops.block_score_value_l2(vc, None, 1, ops.SCORE_CACHE, H, D, bs).item()
+        if dt == 0:
+            assert got == pytest.approx(expect, rel=2e-6) and got_c == pytest.approx(expect, rel=2e-6)
+        else:
+            assert got == expect and got_c == expect, (c, got, got_c, expect)
+
+
+def test_block_score_cache_blocks(ops, oracle):
+    g = torch.Generator().manual_seed(9)
+    nb, H, D, bs = 40, 8, 128, 16
+    _, vc = make_cache(nb, H, D, bs, torch.bfloat16, g)
+    ids = torch.tensor([3, 17, 0, 39, 17], dtype=torch.int32)
+    for layout in (1, 2):
+        got = ops.block_score_value_l2(vc.cuda(), ids.cuda(), len(ids), layout, H, D, bs).cpu().tolist()
+        expect = [oracle.block_score(vc[int(b)], bs, H, D, layout) for b in ids]
+        assert got == expect
+
+
+@pytest.mark.parametrize("method", ["streamingLLM", "streamingLLM-1"])
+def test_evict_streaming(ops, oracle, method):
+    bs, budget = 16, 96
+    seq_lens = [50, 96, 97, 112, 113, 128, 200, 208]
+    B = len(seq_lens)
+    M = 16
+    g = torch.Generator().manual_seed(1)
+    tables = torch.randint(0, 1000, (B, M), generator=g, dtype=torch.int32)
+    nblk = torch.tensor([min(M, -(-L // bs)) for L in seq_lens], dtype=torch.int32)
+    rmv_e, zero_e = oracle.decode_streaming(seq_lens, tables.tolist(), budget, bs, method)
+    rmv, out, zero = ops.evict_select_compact(tables.cuda(), torch.tensor(seq_lens, dtype=torch.int32).cuda(),
+                                              nblk.cuda(), method, budget, bs)
+    assert rmv.cpu().tolist() == rmv_e
+    assert torch.equal(out.cpu(), oracle.compact_block_tables(tables, rmv_e))
+    if method == "streamingLLM-1":
+        assert [z for z in zero.cpu().tolist() if z >= 0] == zero_e
+    # reference-compatible (quirk) compaction
+    _, out_q1, _ = ops.evict_select_compact(tables.cuda(), torch.tensor(seq_lens, dtype=torch.int32).cuda(),
+                                            nblk.cuda(), method, budget, bs, compat_q1=True)
+    assert torch.equal(out_q1.cpu(), oracle.compact_block_tables(tables, rmv_e, compat_q1=True))
+
+
+@pytest.mark.parametrize("method,topk", [("global", -1), ("local", 3)])
+@pytest.mark.parametrize("drop", [True, False])
+@pytest.mark.parametrize("layout", [1, 2])
+def test_evict_topk_trace(ops, oracle, method, topk, drop, layout):
+    """Multi-step decode trace: device score table + victim choice vs the restated
+    _prune_decode_reqs_topk with value_l2 scores (random off)."""
+    g = torch.Generator().manual_seed(21)
+    bs, budget, H, D, nb = 16, 64, 8, 128, 128
+    _, vc = make_cache(nb, H, D, bs, torch.bfloat16, g)
+    vc_d = vc.cuda()
+    B, W = 3, 32
+    # per sequence: host model = list of physical blocks + list of scores
+    tables = [torch.randperm(nb, generator=g)[:n].tolist() for n in (4, 5, 4)]
+    seq_len = [64, 80, 63]
+    scores = [[oracle.block_score(vc[b], bs, H, D, layout) for b in t] for t in tables]
+    table_d = torch.zeros((B, W), dtype=torch.float32)
+    counts = torch.zeros(B, dtype=torch.int32)
+    for i, s in enumerate(scores):
+        table_d[i, :len(s)] = torch.tensor(s)
+        counts[i] = len(s)
+    # sequences use score rows in a permuted order to exercise score_rows
+    rows = torch.tensor([2, 0, 1], dtype=torch.int32)
+    st = torch.zeros((B, W), dtype=torch.float32)
+    sc = torch.zeros(B, dtype=torch.int32)
+    for i in range(B):
+        st[rows[i]] = table_d[i]
+        sc[rows[i]] = counts[i]
+    st_d, sc_d, rows_d = st.cuda(), sc.cuda(), rows.cuda()
+    free = [b for b in range(nb) if all(b not in t for t in tables)]
+    kv_len = list(seq_len)
+    for step in range(70):
+        for i in range(B):
+            seq_len[i] += 1
+            kv_len[i] += 1
+            if kv_len[i] > len(tables[i]) * bs:  # last block full -> the scheduler appends one
+                tables[i].append(free.pop(0))
+        M = max(len(t) for t in tables)
+        bt = torch.zeros((B, M), dtype=torch.int32)
+        for i, t in enumerate(tables):
+            bt[i, :len(t)] = torch.tensor(t)
+        nblk = torch.tensor([len(t) for t in tables], dtype=torch.int32)
+        rmv, out, _ = ops.evict_select_compact(
+            bt.cuda(), torch.tensor(seq_len, dtype=torch.int32).cuda(), nblk.cuda(), method, budget, bs,
+            topk, drop_victim_score=drop, score_layout=layout, score_table=st_d, score_counts=sc_d,
+            score_rows=rows_d, value_cache=vc_d)
+        rmv = rmv.cpu().tolist()
+        expect = []
+        for i in range(B):
+            if oracle.decode_trigger(seq_len[i], budget, bs):
+                new = oracle.block_score(vc[tables[i][-1]], bs, H, D, layout)
+                expect.append(oracle.decode_topk_victim(scores[i], new, method, topk, drop))
+            else:
+                expect.append(-1)
+        assert rmv == expect, (step, rmv, expect)
+        assert torch.equal(out.cpu(), oracle.compact_block_tables(bt, expect))
+        for i in range(B):
+            if expect[i] >= 0:
+                free.append(tables[i].pop(expect[i]))
+                kv_len[i] -= bs
+    got_counts = sc_d.cpu()
+    got_table = st_d.cpu()
+    for i in range(B):
+        n = int(got_counts[rows[i]])
+        assert n == len(scores[i])
+        assert got_table[rows[i], :n].tolist() == scores[i]
+
+
+def test_evict_victim_override(ops, oracle):
+    """Host-chosen victims (the reference's random mode) are applied verbatim."""
+    bs, budget = 16, 64
+    tables = torch.arange(0, 3 * 8, dtype=torch.int32).reshape(3, 8)
+    seq_lens = torch.tensor([128, 100, 112], dtype=torch.int32)
+    nblk = torch.tensor([8, 7, 7], dtype=torch.int32)
+    ov = torch.tensor([5, 3, 2], dtype=torch.int32)
+    rmv, out, _ = ops.evict_select_compact(tables.cuda(), seq_lens.cuda(), nblk.cuda(), "global", budget, bs,
+                                           victim_override=ov.cuda())
+    assert rmv.cpu().tolist() == [5, -1, 2]
+    assert torch.equal(out.cpu(), oracle.compact_block_tables(tables, [5, -1, 2]))

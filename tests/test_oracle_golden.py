@@ -1,0 +1,144 @@
+"""Pins the CPU oracle against golden vectors produced by the reference's own code
+(tests/golden/make_golden.py): KVCachePruner, BlockL2NormManager and the reference's
+CPU kernels."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, from_bits
+
+
+def test_pruned_length_table(oracle):
+    tab = json.load(open(os.path.join(GOLDEN, "prune_tables.json")))
+    for bs, budget, method, L, expect in tab["pruned_length"]:
+        assert oracle.pruned_length(L, budget, bs) == expect, (bs, budget, method, L)
+        if L >= budget and budget >= 3 * bs:
+            nblk, ntok = oracle.num_required_blocks_after_prune(L, budget, bs)
+            assert ntok == expect and nblk == -(-expect // bs)
+
+
+def test_streaming_keep_indices(oracle):
+    tab = json.load(open(os.path.join(GOLDEN, "prune_tables.json")))
+    for c in tab["streaming_keep"]:
+        assert oracle.streaming_keep_indices(c["L"], c["budget"], c["bs"]) == c["kept"], c
+
+
+def test_worked_examples(oracle):
+    # kvcache_prunner.py prompt prune, L=1024, bs=16, budget=768:
+    kept = oracle.streaming_keep_indices(1024, 768, 16)
+    assert kept == list(range(0, 16)) + list(range(272, 1008)) + list(range(1008, 1024))
+    assert oracle.pruned_length(1030, 512, 16) == 518
+    assert oracle.num_required_blocks_after_prune(1030, 512, 16) == (33, 518)
+    assert oracle.num_required_blocks_after_prune(1024, 768, 16) == (48, 768)
+
+
+def test_prompt_prune_topk_golden(oracle):
+    z = np.load(os.path.join(GOLDEN, "prompt_prune_topk.npz"))
+    n = len([k for k in z.files if k.endswith("_meta")])
+    assert n >= 18
+    for c in range(n):
+        L, budget, bs, H, D, m = [int(v) for v in z[f"c{c}_meta"]]
+        method = ["global", "local", "inverse_key_l2"][m]
+        k, v = from_bits(z[f"c{c}_k"], 0), from_bits(z[f"c{c}_v"], 0)
+        pk, pv = oracle.prompt_prune(k, v, method, budget, bs, compat_q2=True)
+        assert torch.equal(pk, from_bits(z[f"c{c}_pk"], 0)), c
+        assert torch.equal(pv, from_bits(z[f"c{c}_pv"], 0)), c
+        # per-head (intended) compaction keeps the same multiset of rows per head
+        ik, iv = oracle.prompt_prune(k, v, method, budget, bs, compat_q2=False)
+        assert ik.shape == pk.shape
+        scores = oracle.token_scores(k[bs:L - bs - L % bs], v[bs:L - bs - L % bs], method)
+        keep = oracle.topk_keep_mask(scores, oracle.prompt_slices(L, budget, bs)[2])
+        for h in range(H):
+            assert torch.equal(ik[bs:ik.shape[0] - bs - L % bs, h],
+                               k[bs:L - bs - L % bs][keep[:, h], h])
+
+
+def test_block_score_golden(oracle):
+    z = np.load(os.path.join(GOLDEN, "block_scores.npz"))
+    n = len([k for k in z.files if k.endswith("_meta")])
+    assert n == 18
+    for c in range(n):
+        bs, H, D, dt = [int(v) for v in z[f"c{c}_meta"]]
+        v = from_bits(z[f"c{c}_v"], dt)
+        expect = from_bits(z[f"c{c}_score"], dt).float().item()
+        got = oracle.block_score(v, bs, H, D, layout=0)
+        # the same logical rows fetched from the paged value-cache layout [H, D, bs]
+        vc = v.permute(1, 2, 0).contiguous()
+        got_c = oracle.block_score(vc, bs, H, D, layout=1)
+        if dt == 0:
+            # f32 storage: torch's vectorised reduction order is not reproduced (a few ulp);
+            # the 16-bit types, where every partial sum is exact, must match bit for bit
+            assert got == pytest.approx(expect, rel=2e-6) and got_c == got
+        else:
+            assert got == expect, (c, got, expect)
+            assert got_c == expect
+
+
+def test_block_score_compat_layout(oracle):
+    # reference decode call site views the flat cache block as [-1, H, D]
+    # (torch_cuda_sdpa.py:1521-1524); restated by layout=2.
+    g = torch.Generator().manual_seed(3)
+    vc = (torch.rand(8, 128, 16, generator=g) - 0.5).to(torch.bfloat16)
+    view = vc.reshape(-1).view(-1, 8, 128)
+    expect = torch.norm(view, p=2, dim=-1).mean(dim=1).sum(dim=0).float().item()
+    assert oracle.block_score(vc, 16, 8, 128, layout=2) == expect
+
+
+def test_ref_cpu_kernels_golden(oracle):
+    z = np.load(os.path.join(GOLDEN, "ref_cpu_kernels.npz"))
+    n = len([k for k in z.files if k.endswith("_meta")])
+    for c in range(n):
+        Hq, Hkv, D, bs, nb, dt = [int(v) for v in z[f"c{c}_meta"]]
+        x = 16 // (4 if dt == 0 else 2)
+        k, v = from_bits(z[f"c{c}_k"], dt), from_bits(z[f"c{c}_v"], dt)
+        slots = torch.from_numpy(z[f"c{c}_slots"])
+        kc = torch.zeros(nb, Hkv, D // x, bs, x, dtype=k.dtype)
+        vc = torch.zeros(nb, Hkv, D, bs, dtype=k.dtype)
+        oracle.reshape_and_cache(k, v, kc, vc, slots)
+        assert torch.equal(kc, from_bits(z[f"c{c}_kc_out"], dt))
+        assert torch.equal(vc, from_bits(z[f"c{c}_vc_out"], dt))
+        q = from_bits(z[f"c{c}_q"], dt)
+        out = oracle.paged_attention(q, kc, vc, torch.from_numpy(z[f"c{c}_bt"]),
+                                     torch.from_numpy(z[f"c{c}_lens"]), D ** -0.5)
+        ref = from_bits(z[f"c{c}_o"], dt)
+        # the reference CPU kernel keeps f32 probabilities and has no 1e-6 term
+        # (csrc/cpu/attention.cpp:82-105); the oracle follows the CUDA kernel
+        # (bf16-rounded probabilities): tolerance of tests/kernels/test_attention.py:323-331
+        torch.testing.assert_close(out.float(), ref.float(), atol=1e-3, rtol=1.6e-2)
+
+
+def test_l2norm_manager_golden():
+    import vllm_paged_compression_amd.block_l2norm_manager as m
+    g = json.load(open(os.path.join(GOLDEN, "l2norm_manager.json")))
+    mgr = m.BlockL2NormManager()
+    for st in g["steps"]:
+        mgr.update_reqs({r: {int(s): b for s, b in v.items()} for r, v in st["input"].items()})
+        assert [[r, s] for r, s in mgr.flat_sequence_map] == st["flat_sequence_map"]
+        assert sorted(mgr.reqid_mapping_block_l2norms.keys()) == st["norm_keys"]
+    mgr.update_block_l2norms(0, [1.0, 2.0, 3.0])
+    assert list(mgr.update_last_block_l2norm(0, 0.5)) == g["after_append"]
+    assert list(mgr.get_reqid_and_seqid(0)) == g["seq0"]
+
+
+def test_compaction_quirk_q1(oracle):
+    t = torch.tensor([[10, 11, 12, 13], [20, 21, 22, 23]], dtype=torch.int32)
+    assert oracle.compact_block_tables(t, [1, 1]).tolist() == [[10, 12, 13], [20, 22, 23]]
+    # the reference's in-loop slice (torch_cuda_sdpa.py:1583) corrupts rows >= 1
+    assert oracle.compact_block_tables(t, [1, 1], compat_q1=True).tolist() == [[10, 12, 13], [20, 22, 22]]
+    assert oracle.compact_block_tables(t, [-1, 2]).tolist() == [[10, 11, 12], [20, 21, 23]]
+    assert oracle.compact_block_tables(t[:1], [1], compat_q1=True).tolist() == [[10, 12, 13]]
+
+
+def test_decode_trace_streaming(oracle):
+    # 1024 -> 100 at budget 768, block 16: six evictions at seq_len 1040..1120,
+    # kv_len stays in [768, 784]
+    tr = oracle.simulate_streaming_generation(1024, 100, 768, 16)
+    ev = [s for s, _, _, r in tr if r >= 0]
+    assert ev == [1040, 1056, 1072, 1088, 1104, 1120]
+    assert min(k for _, k, _, _ in tr) >= 768 and max(k for _, k, _, _ in tr) <= 784
+    assert all(r in (-1, 1) for _, _, _, r in tr)
+    tr = oracle.simulate_streaming_generation(1024, 100, 512, 16)
+    assert min(k for _, k, _, _ in tr) >= 512 and max(k for _, k, _, _ in tr) <= 528

@@ -1,0 +1,271 @@
+// Eviction scoring and the per-step eviction decision on gfx950:
+//   pe_block_score_value_l2   per-block value_l2 score
+//   pe_evict_select_compact   trigger + victim choice + score bookkeeping + block-table
+//                             compaction (+ streamingLLM-1 zero-slot ids), one launch/step
+// Integer / small-FP work: one 64-lane wave per block or per sequence; the byte traffic is
+// one 32 KiB value block per scored block plus the block tables.
+#include "pe_common.h"
+
+namespace pe {
+
+constexpr int SCORE_MAX_PAIRS = 64 * 64;  // block_size * num_kv_heads held in LDS
+
+// Score of one block, computed by one wave.  Follows torch's evaluation of
+//   norm(V, dim=-1).mean(dim=1).sum(dim=0)
+// on a low-precision tensor: every reduction accumulates in f32 and its result is rounded
+// to the storage type.  The sum of squares runs over d in ascending order in one lane
+// (products of 16-bit values are exact in f32, so only this order matters).
+template <typename T>
+__device__ float block_score_wave(const T* __restrict__ base, int layout, int num_kv_heads,
+                                  int head_size, int block_size, float* norms /* LDS [bs*H] */,
+                                  float* means /* LDS [bs] */) {
+  const int lane = threadIdx.x & 63;
+  const int pairs = block_size * num_kv_heads;
+  for (int p = lane; p < pairs; p += 64) {
+    // pair p = (row t, head h) of the [block_size, H, D] view
+    const int t = p / num_kv_heads, h = p % num_kv_heads;
+    float ss = 0.f;
+    if (layout == PE_SCORE_CACHE) {
+      const T* v = base + (int64_t)h * head_size * block_size + t;  // V[h][d][t]
+      for (int d = 0; d < head_size; ++d) {
+        const float x = to_f32(v[(int64_t)d * block_size]);
+        ss += x * x;
+      }
+    } else {
+      const T* v = base + (int64_t)p * head_size;  // dense rows (token-major or flat re-view)
+      for (int d = 0; d < head_size; ++d) {
+        const float x = to_f32(v[d]);
+        ss += x * x;
+      }
+    }
+    norms[p] = round_to<T>(sqrtf(ss));
+  }
+  __syncthreads();
+  for (int t = lane; t < block_size; t += 64) {
+    float hs = 0.f;
+    for (int h = 0; h < num_kv_heads; ++h) hs += norms[t * num_kv_heads + h];
+    means[t] = round_to<T>(hs / (float)num_kv_heads);
+  }
+  __syncthreads();
+  float total = 0.f;
+  for (int t = 0; t < block_size; ++t) total += means[t];
+  return round_to<T>(total);
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void block_score_kernel(float* __restrict__ scores,
+                                                         const T* __restrict__ values,
+                                                         const int32_t* __restrict__ block_ids,
+                                                         int layout, int64_t block_stride,
+                                                         int num_kv_heads, int head_size,
+                                                         int block_size) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* norms = reinterpret_cast<float*>(smem);
+  float* means = norms + block_size * num_kv_heads;
+  const int i = blockIdx.x;
+  const int64_t blk = block_ids ? block_ids[i] : i;
+  const float s = block_score_wave<T>(values + blk * block_stride, layout, num_kv_heads, head_size,
+                                      block_size, norms, means);
+  if (threadIdx.x == 0) scores[i] = s;
+}
+
+// One wave per sequence (grid = batch), or a single wave walking all rows serially when the
+// reference's in-loop slice has to be reproduced (compat_q1).
+template <typename T>
+__global__ __launch_bounds__(64) void evict_select_compact_kernel(
+    int32_t* __restrict__ rmv_idx_out, int32_t* __restrict__ out_tables,
+    int64_t* __restrict__ zero_slots_out, const int32_t* __restrict__ block_tables,
+    const int32_t* __restrict__ seq_lens, const int32_t* __restrict__ num_blocks,
+    const int32_t* __restrict__ victim_override, int batch, int max_blocks, int method,
+    int cache_budget, int block_size, int topk_blocks, int drop_victim_score, int compat_q1,
+    int score_layout, float* __restrict__ score_table, int32_t* __restrict__ score_counts,
+    const int32_t* __restrict__ score_rows, int score_table_width,
+    const T* __restrict__ value_cache, int64_t kv_block_stride, int num_kv_heads, int head_size) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* norms = reinterpret_cast<float*>(smem);
+  float* means = norms + block_size * num_kv_heads;
+  const int lane = threadIdx.x;
+  const int b_begin = compat_q1 ? 0 : blockIdx.x;
+  const int b_end = compat_q1 ? batch : blockIdx.x + 1;
+  const int w = max_blocks - 1;
+
+  for (int b = b_begin; b < b_end; ++b) {
+    const int seq_len = seq_lens[b];
+    const int32_t* row = block_tables + (int64_t)b * max_blocks;
+    int rmv = -1;
+    int64_t zslot = -1;
+    const bool over = seq_len > cache_budget;
+    const bool boundary = (seq_len % block_size) == 0;
+    if (over && !boundary && method == PE_EVICT_STREAMING_1) {
+      zslot = (int64_t)row[1] * block_size + (seq_len % block_size) - 1;
+    }
+    if (over && boundary && method != PE_EVICT_INVERSE_KEY_L2) {
+      if (method == PE_EVICT_STREAMING || method == PE_EVICT_STREAMING_1) {
+        rmv = 1;
+      } else {
+        const int ov = victim_override ? victim_override[b] : -1;
+        if (score_table != nullptr) {
+          // score the just-filled block and append it to this sequence's list
+          const int srow = score_rows[b];
+          float* list = score_table + (int64_t)srow * score_table_width;
+          int n = score_counts[srow];
+          const int last_blk = row[num_blocks[b] - 1];
+          const float s = block_score_wave<T>(value_cache + (int64_t)last_blk * kv_block_stride,
+                                              score_layout, num_kv_heads, head_size, block_size,
+                                              norms, means);
+          // the appended entry is kept in a register (every lane holds s): entries written
+          // in this launch are never read back through memory
+          int n_new = -1;
+          if (n < score_table_width) {
+            if (lane == 0) list[n] = s;
+            n_new = n;
+            n += 1;
+          }
+          int start = 1, end = (method == PE_EVICT_LOCAL) ? 1 + topk_blocks : n - 1;
+          if (end > n) end = n;
+          // first arg-min over [start, end): strict '<' keeps the earliest minimum
+          int best = start;
+          if (ov >= 0) {
+            best = ov;
+          } else {
+            float bv = (start < n) ? (start == n_new ? s : list[start]) : 0.f;
+            int bi = start;
+            for (int i = start + lane; i < end; i += 64) {
+              const float v = (i == n_new) ? s : list[i];
+              if (v < bv || (v == bv && i < bi)) {
+                bv = v;
+                bi = i;
+              }
+            }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+              const float ov2 = __shfl_xor(bv, m);
+              const int oi = __shfl_xor(bi, m);
+              if (ov2 < bv || (ov2 == bv && oi < bi)) {
+                bv = ov2;
+                bi = oi;
+              }
+            }
+            best = bi;
+          }
+          rmv = best;
+          if (drop_victim_score && best < n) {
+            // delete the victim's entry: shift the tail left by one (chunked so that reads of a
+            // chunk complete before its writes)
+            for (int base = best; base < n - 1; base += 64) {
+              const int i = base + lane;
+              float v = 0.f;
+              if (i < n - 1) v = (i + 1 == n_new) ? s : list[i + 1];
+              __syncthreads();
+              if (i < n - 1) list[i] = v;
+              __syncthreads();
+            }
+            n -= 1;
+          }
+          if (lane == 0) score_counts[srow] = n;
+        } else {
+          rmv = ov;  // host-chosen victim (random mode) without score bookkeeping
+        }
+      }
+    }
+    if (lane == 0) {
+      rmv_idx_out[b] = rmv;
+      if (zero_slots_out) zero_slots_out[b] = zslot;
+    }
+    if (out_tables != nullptr && w > 0) {
+      int32_t* o = out_tables + (int64_t)b * w;
+      if (!compat_q1 || b == 0) {
+        for (int j = lane; j < w; j += 64) o[j] = (rmv >= 0 && j >= rmv) ? row[j + 1] : row[j];
+      } else {
+        // rows after the first see a table already cut to width w by the reference's slice
+        // inside its loop: removing a column leaves w-1 new entries and the old last one stays
+        for (int j = lane; j < w; j += 64) {
+          int32_t v;
+          if (rmv >= 0 && rmv < w) {
+            v = (j < rmv) ? row[j] : (j < w - 1 ? row[j + 1] : row[w - 1]);
+          } else {
+            v = row[j];
+          }
+          o[j] = v;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace pe
+
+extern "C" {
+
+int pe_block_score_value_l2(float* scores_out, const void* values, const int32_t* block_ids,
+                            int n_blocks, int layout, int64_t block_stride, int num_kv_heads,
+                            int head_size, int block_size, int dtype, void* stream) {
+  using namespace pe;
+  PE_REQUIRE(n_blocks >= 0, PE_ERR_INVALID_ARG, "negative n_blocks");
+  if (n_blocks == 0) return PE_OK;
+  PE_REQUIRE(scores_out && values, PE_ERR_INVALID_ARG, "block_score: null pointer");
+  PE_REQUIRE(layout >= 0 && layout <= 2, PE_ERR_INVALID_ARG, "block_score: bad layout %d", layout);
+  PE_REQUIRE(num_kv_heads > 0 && head_size > 0 && block_size > 0, PE_ERR_INVALID_ARG,
+             "block_score: bad sizes");
+  PE_REQUIRE(block_size * num_kv_heads <= SCORE_MAX_PAIRS, PE_ERR_UNSUPPORTED,
+             "block_size*num_kv_heads too large for the score kernel");
+  const size_t lds = (size_t)(block_size * num_kv_heads + block_size) * 4;
+  PE_DISPATCH_ALL(dtype, T,
+                  hipLaunchKernelGGL(block_score_kernel<T>, dim3((unsigned)n_blocks), dim3(64), lds,
+                                     static_cast<hipStream_t>(stream), scores_out, (const T*)values,
+                                     block_ids, layout, block_stride, num_kv_heads, head_size,
+                                     block_size));
+  return check_launch("block_score_value_l2");
+}
+
+int pe_evict_select_compact(int32_t* rmv_idx_out, int32_t* out_tables, int64_t* zero_slots_out,
+                            const int32_t* block_tables, const int32_t* seq_lens,
+                            const int32_t* num_blocks, const int32_t* victim_override, int batch,
+                            int max_blocks, int method, int cache_budget, int block_size,
+                            int topk_blocks, int drop_victim_score, int compat_q1,
+                            int score_layout, float* score_table, int32_t* score_counts,
+                            const int32_t* score_rows, int score_table_width,
+                            const void* value_cache, int64_t kv_block_stride, int num_kv_heads,
+                            int head_size, int dtype, void* stream) {
+  using namespace pe;
+  PE_REQUIRE(batch >= 0, PE_ERR_INVALID_ARG, "negative batch");
+  if (batch == 0) return PE_OK;
+  PE_REQUIRE(rmv_idx_out && block_tables && seq_lens && num_blocks, PE_ERR_INVALID_ARG,
+             "evict_select_compact: null pointer");
+  PE_REQUIRE(method >= PE_EVICT_STREAMING && method <= PE_EVICT_INVERSE_KEY_L2, PE_ERR_INVALID_ARG,
+             "unknown eviction method %d", method);
+  PE_REQUIRE(block_size > 0 && max_blocks >= 2 && cache_budget >= 3 * block_size,
+             PE_ERR_INVALID_ARG,
+             "need block_size > 0, a table at least 2 blocks wide and a budget of >= 3 blocks");
+  PE_REQUIRE(method != PE_EVICT_STREAMING_1 || zero_slots_out, PE_ERR_INVALID_ARG,
+             "streamingLLM-1 needs zero_slots_out");
+  size_t lds = 0;
+  if (method == PE_EVICT_LOCAL || method == PE_EVICT_GLOBAL) {
+    PE_REQUIRE(method != PE_EVICT_LOCAL || topk_blocks > 1, PE_ERR_INVALID_ARG,
+               "Topk blocks must be > 1 when using 'local' evict method");
+    PE_REQUIRE(score_table || victim_override, PE_ERR_INVALID_ARG,
+               "local/global need a score table or host-chosen victims");
+    if (score_table) {
+      PE_REQUIRE(score_counts && score_rows && value_cache && score_table_width > 2,
+                 PE_ERR_INVALID_ARG, "score bookkeeping arguments missing");
+      PE_REQUIRE(num_kv_heads > 0 && head_size > 0 && block_size * num_kv_heads <= SCORE_MAX_PAIRS,
+                 PE_ERR_INVALID_ARG, "bad head layout for block scoring");
+      PE_REQUIRE(score_layout == PE_SCORE_CACHE || score_layout == PE_SCORE_CACHE_FLAT,
+                 PE_ERR_INVALID_ARG, "decode-time scores read the paged cache (layout 1 or 2)");
+      lds = (size_t)(block_size * num_kv_heads + block_size) * 4;
+    }
+  }
+  const unsigned grid = compat_q1 ? 1u : (unsigned)batch;
+  PE_DISPATCH_ALL(dtype, T,
+                  hipLaunchKernelGGL(evict_select_compact_kernel<T>, dim3(grid), dim3(64), lds,
+                                     static_cast<hipStream_t>(stream), rmv_idx_out, out_tables,
+                                     zero_slots_out, block_tables, seq_lens, num_blocks,
+                                     victim_override, batch, max_blocks, method, cache_budget,
+                                     block_size, topk_blocks, drop_victim_score, compat_q1,
+                                     score_layout, score_table, score_counts, score_rows,
+                                     score_table_width, (const T*)value_cache, kv_block_stride,
+                                     num_kv_heads, head_size));
+  return check_launch("evict_select_compact");
+}
+
+}  // extern "C"

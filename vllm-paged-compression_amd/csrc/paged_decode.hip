@@ -1,0 +1,472 @@
+// Single-query ("decode") attention over a paged KV cache on gfx950.
+//
+// Fast path (16-bit types, block_size 16, head_size in {64,128,256}, up to 16 query
+// heads per KV head): one workgroup per (KV split, KV head, sequence); all query heads
+// that share the KV head are processed together, so every K and V byte is read from
+// HBM once.  K and V go straight from global memory into MFMA operand registers —
+// the reference's paged layouts already are MFMA fragment layouts for 16-token blocks:
+//
+//   key_cache block  [D/8][16 tok][8]   : lane l of the wave reads 16 bytes at
+//                    kstep*1024 + l*16  = A fragment (row = token l&15,
+//                    k = 8*(l>>4)+j) of v_mfma_f32_16x16x32 for S^T = K.Q^T;
+//   value_cache block [D][16 tok]       : lane l reads 8 bytes (4 tokens 4*(l>>4)..)
+//                    of row d = 16*dt + (l&15) from each of two blocks = A fragment of
+//                    O^T += V^T.P^T, with the 32 k-slots of the MFMA ordered
+//                    (lane group g, j<4) -> block A token 4g+j, (g, j>=4) -> block B
+//                    token 4g+j-4, which is exactly how the S^T accumulators of the two
+//                    blocks sit in the lanes, so P needs no cross-lane movement.
+//
+// Softmax is the online form in f32; the final normalisation is 1/(sum + 1e-6) as in
+// the reference kernel (csrc/attention/attention_kernels.cuh:342) and P is rounded to
+// the storage type before P.V (:398-400).
+//
+// Generic path (any head size that is a multiple of the 16-byte chunk, any block size,
+// f32 too): one workgroup per (head, sequence), logits staged in LDS like the reference.
+#include <cfloat>
+#include <cstdlib>
+
+#include "pe_common.h"
+
+namespace pe {
+
+constexpr int DEC_WAVES = 4;
+constexpr int DEC_THREADS = DEC_WAVES * 64;
+constexpr float NEG_BIG = -1.0e30f;
+
+template <typename T, int HEAD_SIZE>
+struct DecTile {
+  typename Traits<T>::vec8 k[2][HEAD_SIZE / 32];
+  typename Traits<T>::vec4 v[2][HEAD_SIZE / 16];
+};
+
+// Partial results of one split: [split][seq][head] -> m, l, then O[D] (all f32)
+__host__ __device__ inline int64_t ws_stride(int head_size) { return head_size + 2; }
+
+template <typename T, int HEAD_SIZE>
+__global__ __launch_bounds__(DEC_THREADS, 2) void paged_decode_mfma_kernel(
+    T* __restrict__ out, float* __restrict__ ws, const T* __restrict__ query,
+    const T* __restrict__ key_cache, const T* __restrict__ value_cache,
+    const int32_t* __restrict__ block_tables, const int32_t* __restrict__ seq_lens,
+    const float* __restrict__ alibi_slopes, int num_heads, int num_kv_heads,
+    int max_num_blocks_per_seq, int64_t q_stride, int64_t kv_block_stride,
+    int64_t kv_head_stride, float scale, int num_splits) {
+  using TR = Traits<T>;
+  using vec8 = typename TR::vec8;
+  using vec4 = typename TR::vec4;
+  constexpr int KS = HEAD_SIZE / 32;  // k-steps of S^T = K.Q^T
+  constexpr int DT = HEAD_SIZE / 16;  // d-tiles of O^T
+  constexpr int BS = 16;
+
+  const int split = blockIdx.x;
+  const int kvh = blockIdx.y;
+  const int seq = blockIdx.z;
+  const int num_seqs = gridDim.z;
+  const int gqa = num_heads / num_kv_heads;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4;   // lane group: tokens 4g..4g+3 of a block
+  const int hc = lane & 15;  // query head within the group (column of S^T / O^T)
+
+  const int seq_len = seq_lens[seq];
+  const int n_blocks = (seq_len + BS - 1) / BS;
+  const int n_pairs = (n_blocks + 1) / 2;
+  const int pairs_per_split = (n_pairs + num_splits - 1) / num_splits;
+  const int pair_begin = split * pairs_per_split;
+  const int pair_end = min(n_pairs, pair_begin + pairs_per_split);
+  const int32_t* table = block_tables + (int64_t)seq * max_num_blocks_per_seq;
+
+  // ---- Q fragments: B operand, lane holds Q[head hc][32*ks + 8g .. +8) ------------
+  vec8 qf[KS];
+  {
+    const int head = kvh * gqa + hc;
+    const T* qp = query + (int64_t)seq * q_stride + (int64_t)head * HEAD_SIZE + 8 * g;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      u32x4 raw = {0u, 0u, 0u, 0u};
+      if (hc < gqa) raw = *reinterpret_cast<const u32x4*>(qp + 32 * ks);
+      qf[ks] = __builtin_bit_cast(vec8, raw);
+    }
+  }
+  const float slope =
+      (alibi_slopes != nullptr && hc < gqa) ? alibi_slopes[kvh * gqa + hc] : 0.f;
+
+  float m_run = NEG_BIG;  // running max of head hc (same in the 4 lanes sharing hc)
+  float l_run = 0.f;      // this lane's share of the running sum
+  f32x4 acc[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int64_t head_off = (int64_t)kvh * kv_head_stride;
+  const int k_lane_off = lane * 8;               // elements
+  const int v_lane_off = hc * BS + 4 * g;        // elements, + dt*16*BS
+
+  auto issue = [&](DecTile<T, HEAD_SIZE>& t, int pair) {
+    const int ia = 2 * pair;
+    const int ib = min(2 * pair + 1, n_blocks - 1);  // odd tail: re-read A's neighbour, masked
+    const int64_t pa = __builtin_amdgcn_readfirstlane(table[ia]);
+    const int64_t pb = __builtin_amdgcn_readfirstlane(table[ib]);
+    const T* ka = key_cache + pa * kv_block_stride + head_off + k_lane_off;
+    const T* kb = key_cache + pb * kv_block_stride + head_off + k_lane_off;
+    const T* va = value_cache + pa * kv_block_stride + head_off + v_lane_off;
+    const T* vb = value_cache + pb * kv_block_stride + head_off + v_lane_off;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      t.k[0][ks] = __builtin_bit_cast(vec8, *reinterpret_cast<const u32x4*>(ka + ks * 512));
+      t.k[1][ks] = __builtin_bit_cast(vec8, *reinterpret_cast<const u32x4*>(kb + ks * 512));
+    }
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      t.v[0][dt] = __builtin_bit_cast(vec4, *reinterpret_cast<const u32x2*>(va + dt * 16 * BS));
+      t.v[1][dt] = __builtin_bit_cast(vec4, *reinterpret_cast<const u32x2*>(vb + dt * 16 * BS));
+    }
+  };
+
+  auto compute = [&](const DecTile<T, HEAD_SIZE>& t, int pair) {
+    f32x4 s[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      s[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) s[b] = TR::mfma16(t.k[b][ks], qf[ks], s[b]);
+    }
+    float mx = NEG_BIG;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int tok0 = (2 * pair + b) * BS + 4 * g;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int tok = tok0 + r;
+        float x = s[b][r] * scale + slope * (float)(tok - seq_len + 1);
+        x = tok < seq_len ? x : NEG_BIG;
+        s[b][r] = x;
+        mx = fmaxf(mx, x);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __expf(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+    vec8 pf;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __expf(s[b][r] - m_new);
+        psum += p;
+        pf[b * 4 + r] = (T)p;
+      }
+    }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      acc[dt] *= alpha;
+      vec8 vf;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        vf[j] = t.v[0][dt][j];
+        vf[4 + j] = t.v[1][dt][j];
+      }
+      acc[dt] = TR::mfma16(vf, pf, acc[dt]);
+    }
+  };
+
+  // ---- main loop: waves interleave over the split's block pairs ----------------------
+  if constexpr (HEAD_SIZE <= 128) {
+    // two tiles in flight per wave (the next pair's 16 KB is requested before the current
+    // pair is consumed)
+    DecTile<T, HEAD_SIZE> t0, t1;
+    int p = pair_begin + wave;
+    if (p < pair_end) {
+      issue(t0, p);
+      while (true) {
+        if (p + DEC_WAVES < pair_end) issue(t1, p + DEC_WAVES);
+        compute(t0, p);
+        p += DEC_WAVES;
+        if (p >= pair_end) break;
+        if (p + DEC_WAVES < pair_end) issue(t0, p + DEC_WAVES);
+        compute(t1, p);
+        p += DEC_WAVES;
+        if (p >= pair_end) break;
+      }
+    }
+  } else {
+    // head_size 256: one tile per wave fits the register file; occupancy hides latency
+    DecTile<T, HEAD_SIZE> t0;
+    for (int p = pair_begin + wave; p < pair_end; p += DEC_WAVES) {
+      issue(t0, p);
+      compute(t0, p);
+    }
+  }
+
+  // ---- merge the 4 lane groups' sums, then the waves through LDS -------------------
+  l_run += __shfl_xor(l_run, 16);
+  l_run += __shfl_xor(l_run, 32);
+
+  __shared__ float sm_o[DEC_WAVES][16][HEAD_SIZE + 4];
+  __shared__ float sm_m[DEC_WAVES][16];
+  __shared__ float sm_l[DEC_WAVES][16];
+  if (hc < gqa) {
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+      *reinterpret_cast<f32x4*>(&sm_o[wave][hc][16 * dt + 4 * g]) = acc[dt];
+    if (g == 0) {
+      sm_m[wave][hc] = m_run;
+      sm_l[wave][hc] = l_run;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < gqa * HEAD_SIZE; i += DEC_THREADS) {
+    const int h = i / HEAD_SIZE, d = i % HEAD_SIZE;
+    float m_tot = sm_m[0][h];
+#pragma unroll
+    for (int w = 1; w < DEC_WAVES; ++w) m_tot = fmaxf(m_tot, sm_m[w][h]);
+    float o = 0.f, l = 0.f;
+#pragma unroll
+    for (int w = 0; w < DEC_WAVES; ++w) {
+      const float f = __expf(sm_m[w][h] - m_tot);
+      o += f * sm_o[w][h][d];
+      l += f * sm_l[w][h];
+    }
+    const int head = kvh * gqa + h;
+    if (num_splits == 1) {
+      out[((int64_t)seq * num_heads + head) * HEAD_SIZE + d] = (T)(o * (1.f / (l + 1e-6f)));
+    } else {
+      float* w = ws + (((int64_t)split * num_seqs + seq) * num_heads + head) * ws_stride(HEAD_SIZE);
+      if (d == 0) {
+        w[0] = m_tot;
+        w[1] = l;
+      }
+      w[2 + d] = o;
+    }
+  }
+}
+
+// merge of the split partials: grid (num_heads, num_seqs), one thread per d
+template <typename T>
+__global__ void paged_decode_merge_kernel(T* __restrict__ out, const float* __restrict__ ws,
+                                          int num_heads, int head_size, int num_splits) {
+  const int head = blockIdx.x, seq = blockIdx.y, num_seqs = gridDim.y;
+  const int64_t stride = ws_stride(head_size);
+  float m_tot = NEG_BIG;
+  for (int s = 0; s < num_splits; ++s)
+    m_tot = fmaxf(m_tot, ws[(((int64_t)s * num_seqs + seq) * num_heads + head) * stride]);
+  for (int d = threadIdx.x; d < head_size; d += blockDim.x) {
+    float o = 0.f, l = 0.f;
+    for (int s = 0; s < num_splits; ++s) {
+      const float* w = ws + (((int64_t)s * num_seqs + seq) * num_heads + head) * stride;
+      const float f = __expf(w[0] - m_tot);
+      o += f * w[2 + d];
+      l += f * w[1];
+    }
+    out[((int64_t)seq * num_heads + head) * head_size + d] = (T)(o * (1.f / (l + 1e-6f)));
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Generic path: the reference's three passes (logits -> softmax -> P.V), one workgroup of
+// 256 threads per (head, sequence), logits in dynamic LDS.
+template <typename T>
+__global__ __launch_bounds__(256) void paged_decode_generic_kernel(
+    T* __restrict__ out, const T* __restrict__ query, const T* __restrict__ key_cache,
+    const T* __restrict__ value_cache, const int32_t* __restrict__ block_tables,
+    const int32_t* __restrict__ seq_lens, const float* __restrict__ alibi_slopes, int num_heads,
+    int num_kv_heads, int head_size, int block_size, int max_num_blocks_per_seq, int64_t q_stride,
+    int64_t kv_block_stride, int64_t kv_head_stride, float scale) {
+  constexpr int X = 16 / sizeof(T);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* q_s = reinterpret_cast<float*>(smem);       // [head_size]
+  float* red = q_s + ((head_size + 3) & ~3);          // [8]
+  float* logits = red + 8;                            // [seq_len]
+  const int head = blockIdx.x, seq = blockIdx.y;
+  const int kvh = head / (num_heads / num_kv_heads);
+  const int seq_len = seq_lens[seq];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int32_t* table = block_tables + (int64_t)seq * max_num_blocks_per_seq;
+  const float slope = alibi_slopes ? alibi_slopes[head] : 0.f;
+  for (int d = tid; d < head_size; d += 256)
+    q_s[d] = to_f32(query[(int64_t)seq * q_stride + (int64_t)head * head_size + d]);
+  __syncthreads();
+
+  float mx = -FLT_MAX;
+  for (int t = tid; t < seq_len; t += 256) {
+    const int64_t blk = table[t / block_size];
+    const int off = t % block_size;
+    const T* kp = key_cache + blk * kv_block_stride + (int64_t)kvh * kv_head_stride + (int64_t)off * X;
+    float dot = 0.f;
+    for (int c = 0; c < head_size / X; ++c) {
+      union {
+        u32x4 v;
+        T e[X];
+      } u;
+      u.v = *reinterpret_cast<const u32x4*>(kp + (int64_t)c * block_size * X);
+#pragma unroll
+      for (int e = 0; e < X; ++e) dot += q_s[c * X + e] * to_f32(u.e[e]);
+    }
+    float x = scale * dot;
+    if (slope != 0.f) x += slope * (float)(t - seq_len + 1);
+    logits[t] = x;
+    mx = fmaxf(mx, x);
+  }
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+  for (int t = tid; t < seq_len; t += 256) {
+    const float e = __expf(logits[t] - mx);
+    logits[t] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  if (lane == 0) red[4 + wave] = sum;
+  __syncthreads();
+  const float inv = 1.f / (red[4] + red[5] + red[6] + red[7] + 1e-6f);
+  for (int d = tid; d < head_size; d += 256) {
+    float acc = 0.f;
+    for (int t = 0; t < seq_len; ++t) {
+      const int64_t blk = table[t / block_size];
+      const int off = t % block_size;
+      const float p = round_to<T>(logits[t] * inv);
+      acc += p * to_f32(value_cache[blk * kv_block_stride + (int64_t)kvh * kv_head_stride +
+                                    (int64_t)d * block_size + off]);
+    }
+    out[((int64_t)seq * num_heads + head) * head_size + d] = from_f32<T>(acc);
+  }
+}
+
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+
+// number of KV splits: enough workgroups to cover the chip a few times, but at least two
+// block pairs per wave per split
+static int choose_splits(int num_seqs, int num_kv_heads, int max_seq_len) {
+  const int forced = env_int("PE_DECODE_SPLITS", 0);
+  const int n_pairs = (max_seq_len + 31) / 32;
+  int max_splits = n_pairs / (2 * DEC_WAVES);
+  if (max_splits < 1) max_splits = 1;
+  if (max_splits > 64) max_splits = 64;
+  if (forced > 0) return forced < max_splits ? forced : max_splits;
+  const int64_t wgs = (int64_t)num_seqs * num_kv_heads;
+  const int64_t target = 512;  // two workgroups (8 waves) per CU
+  int splits = (int)((target + wgs - 1) / wgs);
+  if (splits < 1) splits = 1;
+  if (splits > max_splits) splits = max_splits;
+  return splits;
+}
+
+static bool mfma_path_ok(int num_heads, int num_kv_heads, int head_size, int block_size,
+                         int dtype, int64_t q_stride, int64_t kv_block_stride,
+                         int64_t kv_head_stride) {
+  if (env_int("PE_DECODE_FORCE_GENERIC", 0)) return false;
+  if (dtype != PE_BF16 && dtype != PE_F16) return false;
+  if (block_size != 16) return false;
+  if (head_size != 64 && head_size != 128 && head_size != 256) return false;
+  if (num_heads / num_kv_heads > 16) return false;
+  if (q_stride % 8 || kv_block_stride % 8 || kv_head_stride % 8) return false;
+  return true;
+}
+
+}  // namespace pe
+
+extern "C" {
+
+int64_t pe_paged_decode_workspace_bytes(int num_seqs, int num_heads, int num_kv_heads,
+                                        int head_size, int block_size, int max_seq_len) {
+  (void)block_size;
+  if (num_seqs <= 0 || num_heads <= 0 || num_kv_heads <= 0) return 0;
+  // sized for the largest split count the heuristic can pick, so a caller may allocate once
+  const int n_pairs = (max_seq_len + 31) / 32;
+  int max_splits = n_pairs / (2 * pe::DEC_WAVES);
+  if (max_splits <= 1) return 0;
+  if (max_splits > 64) max_splits = 64;
+  return (int64_t)max_splits * num_seqs * num_heads * pe::ws_stride(head_size) * 4;
+}
+
+int pe_paged_decode(void* out, const void* query, const void* key_cache, const void* value_cache,
+                    const int32_t* block_tables, const int32_t* seq_lens,
+                    const float* alibi_slopes, int num_seqs, int num_heads, int num_kv_heads,
+                    int head_size, int block_size, int max_num_blocks_per_seq, int64_t q_stride,
+                    int64_t kv_block_stride, int64_t kv_head_stride, float scale, int max_seq_len,
+                    int dtype, void* workspace, int64_t workspace_bytes, void* stream) {
+  using namespace pe;
+  PE_REQUIRE(num_seqs >= 0, PE_ERR_INVALID_ARG, "negative num_seqs");
+  if (num_seqs == 0) return PE_OK;
+  PE_REQUIRE(out && query && key_cache && value_cache && block_tables && seq_lens,
+             PE_ERR_INVALID_ARG, "paged_decode: null pointer");
+  PE_REQUIRE(num_heads > 0 && num_kv_heads > 0 && num_heads % num_kv_heads == 0,
+             PE_ERR_INVALID_ARG, "num_heads %d must be a positive multiple of num_kv_heads %d",
+             num_heads, num_kv_heads);
+  PE_REQUIRE(head_size > 0 && block_size > 0 && max_num_blocks_per_seq > 0 && max_seq_len >= 0,
+             PE_ERR_INVALID_ARG, "paged_decode: bad sizes");
+  PE_REQUIRE((int64_t)max_num_blocks_per_seq * block_size >= max_seq_len, PE_ERR_INVALID_ARG,
+             "block table width %d x block %d cannot hold max_seq_len %d", max_num_blocks_per_seq,
+             block_size, max_seq_len);
+  const int x = 16 / elem_size(dtype);
+  PE_REQUIRE(head_size % x == 0, PE_ERR_UNSUPPORTED, "head_size %d not a multiple of %d", head_size, x);
+  PE_REQUIRE(num_seqs <= 65535 && num_kv_heads <= 65535, PE_ERR_UNSUPPORTED, "grid too large");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+
+  if (mfma_path_ok(num_heads, num_kv_heads, head_size, block_size, dtype, q_stride,
+                   kv_block_stride, kv_head_stride)) {
+    const int splits = choose_splits(num_seqs, num_kv_heads, max_seq_len);
+    float* ws = static_cast<float*>(workspace);
+    if (splits > 1) {
+      const int64_t need = (int64_t)splits * num_seqs * num_heads * ws_stride(head_size) * 4;
+      PE_REQUIRE(workspace && workspace_bytes >= need, PE_ERR_WORKSPACE,
+                 "paged_decode needs %lld workspace bytes, got %lld", (long long)need,
+                 (long long)workspace_bytes);
+    }
+    dim3 grid((unsigned)splits, (unsigned)num_kv_heads, (unsigned)num_seqs);
+#define PE_LAUNCH_DEC(T, HS)                                                                    \
+  hipLaunchKernelGGL((paged_decode_mfma_kernel<T, HS>), grid, dim3(DEC_THREADS), 0, st, (T*)out, \
+                     ws, (const T*)query, (const T*)key_cache, (const T*)value_cache,            \
+                     block_tables, seq_lens, alibi_slopes, num_heads, num_kv_heads,              \
+                     max_num_blocks_per_seq, q_stride, kv_block_stride, kv_head_stride, scale,   \
+                     splits)
+    PE_DISPATCH_16(dtype, T, {
+      if (head_size == 64) PE_LAUNCH_DEC(T, 64);
+      else if (head_size == 128) PE_LAUNCH_DEC(T, 128);
+      else PE_LAUNCH_DEC(T, 256);
+    });
+#undef PE_LAUNCH_DEC
+    if (int rc = check_launch("paged_decode")) return rc;
+    if (splits > 1) {
+      PE_DISPATCH_16(dtype, T,
+                     hipLaunchKernelGGL(paged_decode_merge_kernel<T>,
+                                        dim3((unsigned)num_heads, (unsigned)num_seqs),
+                                        dim3(head_size <= 64 ? 64 : 128), 0, st, (T*)out, ws,
+                                        num_heads, head_size, splits));
+      if (int rc = check_launch("paged_decode_merge")) return rc;
+    }
+    return PE_OK;
+  }
+
+  // generic path
+  const size_t lds = (size_t)(((head_size + 3) & ~3) + 8 + max_seq_len) * 4;
+  PE_REQUIRE(lds <= 160 * 1024, PE_ERR_UNSUPPORTED,
+             "generic decode path holds the logits in LDS: max_seq_len %d too long for "
+             "head_size %d / block_size %d / dtype %d",
+             max_seq_len, head_size, block_size, dtype);
+  PE_REQUIRE(num_heads <= 0x7fffffff, PE_ERR_UNSUPPORTED, "grid too large");
+  dim3 grid((unsigned)num_heads, (unsigned)num_seqs);
+#define PE_LAUNCH_GEN(T)                                                                        \
+  do {                                                                                          \
+    if (lds > 64 * 1024)                                                                        \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&paged_decode_generic_kernel<T>), \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);          \
+    hipLaunchKernelGGL(paged_decode_generic_kernel<T>, grid, dim3(256), lds, st, (T*)out,       \
+                       (const T*)query, (const T*)key_cache, (const T*)value_cache,             \
+                       block_tables, seq_lens, alibi_slopes, num_heads, num_kv_heads, head_size, \
+                       block_size, max_num_blocks_per_seq, q_stride, kv_block_stride,           \
+                       kv_head_stride, scale);                                                  \
+  } while (0)
+  PE_DISPATCH_ALL(dtype, T, PE_LAUNCH_GEN(T));
+#undef PE_LAUNCH_GEN
+  return check_launch("paged_decode_generic");
+}
+
+}  // extern "C"

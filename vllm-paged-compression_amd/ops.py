@@ -1,0 +1,418 @@
+"""Torch-level operators over the C ABI of libpaged_evict.so.
+
+The function names, argument order and argument meaning of ``reshape_and_cache``,
+``paged_attention_v1/v2``, ``copy_blocks`` and ``swap_blocks`` mirror the reference's
+``vllm/_custom_ops.py`` wrappers of ``torch.ops._C`` / ``torch.ops._C_cache_ops``
+(schemas: csrc/torch_bindings.cpp:27-51,430-468), so a caller of those can switch by
+changing the import.  The same callables are registered as ``torch.ops.paged_evict.*``.
+
+Validation lives here (dtypes, devices, contiguity); the kernels get raw device
+pointers and the current HIP stream.  There is no CPU implementation: tensors that are
+not on a GPU raise.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+
+_DT = {torch.float32: _lib.PE_F32, torch.float16: _lib.PE_F16, torch.bfloat16: _lib.PE_BF16}
+
+EVICT_METHODS = {"streamingLLM": 0, "streamingLLM-1": 1, "local": 2, "global": 3,
+                 "inverse_key_l2": 4}
+SCORE_TOKEN_MAJOR, SCORE_CACHE, SCORE_CACHE_FLAT = 0, 1, 2
+
+
+def _dtype_code(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise RuntimeError(f"paged_evict: unsupported dtype {t.dtype}") from None
+
+
+def _need_gpu(*tensors: Optional[torch.Tensor]) -> torch.device:
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("paged_evict ops run on the GPU only (got a %s tensor); "
+                               "there is no CPU fallback" % t.device.type)
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError("paged_evict: tensors on different devices")
+    assert dev is not None
+    return dev
+
+
+def _stream(dev: torch.device) -> int:
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+_workspaces: Dict[Tuple[str, int], torch.Tensor] = {}
+
+
+def _workspace(dev: torch.device, nbytes: int, tag: str = "decode") -> Optional[torch.Tensor]:
+    """Per-device scratch buffer, grown on demand (allocated by torch, outside the C call)."""
+    if nbytes <= 0:
+        return None
+    key = (tag, dev.index if dev.index is not None else torch.cuda.current_device())
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
+        _workspaces[key] = ws
+    return ws
+
+
+def _check_kv_cache_args(kv_cache_dtype: str, k_scale: float, v_scale: float) -> None:
+    if kv_cache_dtype != "auto":
+        # the reference backend rejects fp8 KV (torch_cuda_sdpa.py:769-772)
+        raise NotImplementedError("paged_evict does not support FP8 KV cache "
+                                  f"(kv_cache_dtype={kv_cache_dtype!r})")
+    if k_scale != 1.0 or v_scale != 1.0:
+        raise RuntimeError("paged_evict: k_scale and v_scale must be 1.0")
+
+
+# --------------------------------------------------------------------------------------
+def reshape_and_cache(key: torch.Tensor, value: torch.Tensor, key_cache: torch.Tensor,
+                      value_cache: torch.Tensor, slot_mapping: torch.Tensor,
+                      kv_cache_dtype: str = "auto", k_scale: float = 1.0, v_scale: float = 1.0,
+                      *, src_index: Optional[torch.Tensor] = None,
+                      zero_slots: Optional[torch.Tensor] = None) -> None:
+    """key/value [T, H_kv, D]; key_cache [nb, H_kv, D/x, bs, x]; value_cache [nb, H_kv, D, bs];
+    slot_mapping int64[T].  ``src_index`` (int32 [T] or [T, H_kv]) fuses a row gather into the
+    write; ``zero_slots`` (int64 [n]) zeroes those slots after the write."""
+    _check_kv_cache_args(kv_cache_dtype, k_scale, v_scale)
+    dev = _need_gpu(key, value, key_cache, value_cache, slot_mapping, src_index, zero_slots)
+    if key_cache.dim() != 5 or value_cache.dim() != 4:
+        raise RuntimeError("reshape_and_cache: key_cache must be 5-d and value_cache 4-d")
+    if not (key_cache.is_contiguous() and value_cache.is_contiguous()):
+        raise RuntimeError("reshape_and_cache: caches must be contiguous")
+    nb, H, D, bs = value_cache.shape
+    if key.dim() != 3 or key.shape[1:] != (H, D) or value.shape[1:] != (H, D):
+        raise RuntimeError(f"reshape_and_cache: key/value must be [T, {H}, {D}]")
+    if key.dtype != key_cache.dtype or value.dtype != value_cache.dtype or key.dtype != value.dtype:
+        raise RuntimeError("reshape_and_cache: dtype mismatch between key/value and the caches")
+    if key.stride(2) != 1 or key.stride(1) != D or value.stride(2) != 1 or value.stride(1) != D:
+        raise RuntimeError("reshape_and_cache: key/value rows must be dense")
+    slot_mapping = slot_mapping.flatten()
+    if slot_mapping.dtype != torch.int64 or not slot_mapping.is_contiguous():
+        raise RuntimeError("reshape_and_cache: slot_mapping must be contiguous int64")
+    T = slot_mapping.numel()
+    head_stride = 0
+    if src_index is not None:
+        if src_index.dtype != torch.int32 or not src_index.is_contiguous():
+            raise RuntimeError("reshape_and_cache: src_index must be contiguous int32")
+        if src_index.dim() == 2:
+            if src_index.shape != (T, H):
+                raise RuntimeError("reshape_and_cache: src_index must be [T] or [T, H_kv]")
+            head_stride = 1
+        elif src_index.numel() != T:
+            raise RuntimeError("reshape_and_cache: src_index must be [T] or [T, H_kv]")
+    elif key.shape[0] < T or value.shape[0] < T:
+        raise RuntimeError("reshape_and_cache: fewer key/value rows than slots")
+    nz = 0
+    if zero_slots is not None:
+        if zero_slots.dtype != torch.int64 or not zero_slots.is_contiguous():
+            raise RuntimeError("reshape_and_cache: zero_slots must be contiguous int64")
+        nz = zero_slots.numel()
+    lib = _lib.load()
+    _lib.check(lib.pe_reshape_and_cache(
+        _p(key), _p(value), _p(key_cache), _p(value_cache), _p(slot_mapping), T,
+        key.stride(0), value.stride(0), _p(src_index), head_stride, _p(zero_slots), nz,
+        H, D, bs, nb, _dtype_code(key), _stream(dev)), "reshape_and_cache")
+
+
+def _paged_attention(out, query, key_cache, value_cache, num_kv_heads, scale, block_tables,
+                     seq_lens, block_size, max_seq_len, alibi_slopes, kv_cache_dtype, k_scale,
+                     v_scale, blocksparse_vert_stride) -> None:
+    _check_kv_cache_args(kv_cache_dtype, k_scale, v_scale)
+    if blocksparse_vert_stride is not None and blocksparse_vert_stride > 1:
+        raise ValueError("paged_evict does not support block-sparse attention")
+    dev = _need_gpu(out, query, key_cache, value_cache, block_tables, seq_lens, alibi_slopes)
+    if query.dim() != 3 or out.shape != query.shape:
+        raise RuntimeError("paged_attention: query/out must be [num_seqs, num_heads, head_size]")
+    S, Hq, D = query.shape
+    if key_cache.dim() != 5 or value_cache.dim() != 4:
+        raise RuntimeError("paged_attention: key_cache must be 5-d and value_cache 4-d")
+    nb, Hkv, Dv, bs = value_cache.shape
+    if Hkv != num_kv_heads or Dv != D or bs != block_size:
+        raise RuntimeError("paged_attention: cache shape does not match num_kv_heads/head_size/"
+                           "block_size")
+    if not (query.dtype == key_cache.dtype == value_cache.dtype == out.dtype):
+        raise RuntimeError("paged_attention: dtype mismatch")
+    if query.stride(2) != 1 or query.stride(1) != D or not out.is_contiguous():
+        raise RuntimeError("paged_attention: query rows must be dense and out contiguous")
+    if key_cache.stride(0) != value_cache.stride(0) or key_cache.stride(1) != value_cache.stride(1):
+        raise RuntimeError("paged_attention: key and value cache strides differ")
+    if block_tables.dtype != torch.int32 or seq_lens.dtype != torch.int32:
+        raise RuntimeError("paged_attention: block_tables and seq_lens must be int32")
+    if block_tables.dim() != 2 or block_tables.shape[0] != S or block_tables.stride(1) != 1 \
+            or block_tables.stride(0) != block_tables.shape[1]:
+        raise RuntimeError("paged_attention: block_tables must be contiguous [num_seqs, max_blocks]")
+    if seq_lens.numel() != S or not seq_lens.is_contiguous():
+        raise RuntimeError("paged_attention: seq_lens must be contiguous [num_seqs]")
+    if alibi_slopes is not None and (alibi_slopes.dtype != torch.float32 or alibi_slopes.numel() != Hq):
+        raise RuntimeError("paged_attention: alibi_slopes must be float32[num_heads]")
+    lib = _lib.load()
+    need = lib.pe_paged_decode_workspace_bytes(S, Hq, num_kv_heads, D, block_size, max_seq_len)
+    ws = _workspace(dev, need)
+    _lib.check(lib.pe_paged_decode(
+        _p(out), _p(query), _p(key_cache), _p(value_cache), _p(block_tables), _p(seq_lens),
+        _p(alibi_slopes), S, Hq, num_kv_heads, D, block_size, block_tables.shape[1],
+        query.stride(0), key_cache.stride(0), key_cache.stride(1), float(scale), int(max_seq_len),
+        _dtype_code(query), _p(ws), 0 if ws is None else ws.numel(), _stream(dev)),
+        "paged_attention")
+
+
+def paged_attention_v1(out, query, key_cache, value_cache, num_kv_heads, scale, block_tables,
+                       seq_lens, block_size, max_seq_len, alibi_slopes, kv_cache_dtype="auto",
+                       k_scale=1.0, v_scale=1.0, tp_rank=0, blocksparse_local_blocks=0,
+                       blocksparse_vert_stride=0, blocksparse_block_size=64,
+                       blocksparse_head_sliding_step=0) -> None:
+    _paged_attention(out, query, key_cache, value_cache, num_kv_heads, scale, block_tables,
+                     seq_lens, block_size, max_seq_len, alibi_slopes, kv_cache_dtype, k_scale,
+                     v_scale, blocksparse_vert_stride)
+
+
+def paged_attention_v2(out, exp_sums, max_logits, tmp_out, query, key_cache, value_cache,
+                       num_kv_heads, scale, block_tables, seq_lens, block_size, max_seq_len,
+                       alibi_slopes, kv_cache_dtype="auto", k_scale=1.0, v_scale=1.0, tp_rank=0,
+                       blocksparse_local_blocks=0, blocksparse_vert_stride=0,
+                       blocksparse_block_size=64, blocksparse_head_sliding_step=0) -> None:
+    """Same kernel as v1: the split-KV partition count is chosen inside the library and its
+    partials live in the library's workspace; exp_sums / max_logits / tmp_out are accepted for
+    signature compatibility and left untouched."""
+    _paged_attention(out, query, key_cache, value_cache, num_kv_heads, scale, block_tables,
+                     seq_lens, block_size, max_seq_len, alibi_slopes, kv_cache_dtype, k_scale,
+                     v_scale, blocksparse_vert_stride)
+
+
+def copy_blocks(key_caches: List[torch.Tensor], value_caches: List[torch.Tensor],
+                block_mapping: torch.Tensor) -> None:
+    """block_mapping int64 [num_pairs, 2] (src, dst); copies in every layer's K and V cache."""
+    if len(key_caches) != len(value_caches):
+        raise RuntimeError("copy_blocks: key_caches and value_caches differ in length")
+    if not key_caches or block_mapping.numel() == 0:
+        return
+    dev = _need_gpu(*key_caches, *value_caches)
+    bm = block_mapping.to(device=dev, dtype=torch.int64).contiguous()
+    kp = torch.tensor([t.data_ptr() for t in key_caches], dtype=torch.int64).to(dev)
+    vp = torch.tensor([t.data_ptr() for t in value_caches], dtype=torch.int64).to(dev)
+    lib = _lib.load()
+    _lib.check(lib.pe_copy_blocks(_p(kp), _p(vp), _p(bm), len(key_caches), bm.shape[0],
+                                  key_caches[0][0].numel(), _dtype_code(key_caches[0]),
+                                  _stream(dev)), "copy_blocks")
+
+
+def swap_blocks(src: torch.Tensor, dst: torch.Tensor, block_mapping: torch.Tensor) -> None:
+    """block_mapping: CPU int64 [num_pairs, 2]; src/dst may live on the GPU or the host."""
+    if block_mapping.device.type != "cpu":
+        raise RuntimeError("block_mapping must be on CPU")
+    if src.is_cuda and dst.is_cuda:
+        if src.device != dst.device:
+            raise RuntimeError("src and dst must be on the same GPU")
+        kind, dev = 0, src.device
+    elif src.is_cuda and dst.device.type == "cpu":
+        kind, dev = 1, src.device
+    elif src.device.type == "cpu" and dst.is_cuda:
+        kind, dev = 2, dst.device
+    else:
+        raise RuntimeError("Invalid device combination")
+    bm = block_mapping.to(torch.int64).contiguous()
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        _lib.check(lib.pe_swap_blocks(_p(src), _p(dst), _p(bm), bm.shape[0],
+                                      src[0].numel() * src.element_size(), kind, _stream(dev)),
+                   "swap_blocks")
+
+
+# --------------------------------------------------------------------------------------
+def prefill_causal(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor,
+                   cu_q: torch.Tensor, cu_kv: torch.Tensor, max_q_len: int, scale: float,
+                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Varlen causal attention; query [Tq, Hq, D], key/value [Tkv, Hkv, D]; cu_q/cu_kv int32
+    prefix sums on the GPU.  Query i of a request attends kv rows 0..min(i, Lkv-1)."""
+    dev = _need_gpu(query, key, value, cu_q, cu_kv)
+    if query.dim() != 3 or key.dim() != 3 or value.shape != key.shape:
+        raise RuntimeError("prefill_causal: query [Tq,Hq,D], key/value [Tkv,Hkv,D] expected")
+    Tq, Hq, D = query.shape
+    Hkv = key.shape[1]
+    if key.shape[2] != D or Hq % Hkv:
+        raise RuntimeError("prefill_causal: head layout mismatch")
+    for t in (query, key, value):
+        if t.stride(2) != 1 or t.stride(1) != D:
+            raise RuntimeError("prefill_causal: rows must be dense")
+    if not (query.dtype == key.dtype == value.dtype):
+        raise RuntimeError("prefill_causal: dtype mismatch")
+    if cu_q.dtype != torch.int32 or cu_kv.dtype != torch.int32 or cu_q.numel() != cu_kv.numel():
+        raise RuntimeError("prefill_causal: cu_q/cu_kv must be int32 of equal length")
+    if out is None:
+        out = torch.empty((Tq, Hq, D), dtype=query.dtype, device=dev)
+    lib = _lib.load()
+    _lib.check(lib.pe_prefill_causal(
+        _p(out), _p(query), _p(key), _p(value), _p(cu_q), _p(cu_kv), cu_q.numel() - 1,
+        int(max_q_len), Hq, Hkv, D, query.stride(0), key.stride(0), value.stride(0),
+        out.stride(0), float(scale), _dtype_code(query), _stream(dev)), "prefill_causal")
+    return out
+
+
+def prompt_keep_index_streaming(cu_q: torch.Tensor, cu_kept: torch.Tensor, total_kept: int,
+                                cache_budget: int, block_size: int) -> torch.Tensor:
+    dev = _need_gpu(cu_q, cu_kept)
+    idx = torch.empty(total_kept, dtype=torch.int32, device=dev)
+    lib = _lib.load()
+    _lib.check(lib.pe_prompt_keep_index_streaming(_p(idx), _p(cu_q), _p(cu_kept),
+                                                  cu_q.numel() - 1, cache_budget, block_size,
+                                                  _stream(dev)), "prompt_keep_index_streaming")
+    return idx
+
+
+def prompt_token_select(key: torch.Tensor, value: torch.Tensor, cu_q: torch.Tensor,
+                        cu_kept: torch.Tensor, total_kept: int, cache_budget: int,
+                        block_size: int, method: str, compat_q2: bool = False) -> torch.Tensor:
+    """Per-(token, head) kept-row index [total_kept, H_kv] int32 of the token-level prompt prune."""
+    dev = _need_gpu(key, value, cu_q, cu_kept)
+    T, H, D = key.shape
+    idx = torch.empty((total_kept, H), dtype=torch.int32, device=dev)
+    lib = _lib.load()
+    need = lib.pe_prompt_token_select_workspace_bytes(T, H)
+    ws = _workspace(dev, need, "select")
+    _lib.check(lib.pe_prompt_token_select(
+        _p(idx), _p(key), _p(value), _p(cu_q), _p(cu_kept), cu_q.numel() - 1, cache_budget,
+        block_size, EVICT_METHODS[method], 1 if compat_q2 else 0, key.stride(0), value.stride(0),
+        H, D, _dtype_code(key), _p(ws), 0 if ws is None else ws.numel(), _stream(dev)),
+        "prompt_token_select")
+    return idx
+
+
+def prompt_prune_gather(key: torch.Tensor, value: torch.Tensor, src_index: torch.Tensor,
+                        mode: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Dense gather of kept rows: src_index int32 [n] (rows) or [n, H_kv] (rows per head;
+    ``mode=2``: entries are row*H_kv+head pairs)."""
+    dev = _need_gpu(key, value, src_index)
+    T, H, D = key.shape
+    n = src_index.shape[0]
+    if mode is None:
+        mode = 0 if src_index.dim() == 1 else 1
+    ok = torch.empty((n, H, D), dtype=key.dtype, device=dev)
+    ov = torch.empty((n, H, D), dtype=key.dtype, device=dev)
+    lib = _lib.load()
+    _lib.check(lib.pe_prompt_prune_gather(_p(key), _p(value), _p(ok), _p(ov), _p(src_index), mode,
+                                          n, key.stride(0), value.stride(0), H, D,
+                                          _dtype_code(key), _stream(dev)), "prompt_prune_gather")
+    return ok, ov
+
+
+def block_score_value_l2(values: torch.Tensor, block_ids: Optional[torch.Tensor], n_blocks: int,
+                         layout: int, num_kv_heads: int, head_size: int, block_size: int,
+                         block_stride: Optional[int] = None,
+                         out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    dev = _need_gpu(values, block_ids)
+    if out is None:
+        out = torch.empty(n_blocks, dtype=torch.float32, device=dev)
+    if block_stride is None:
+        block_stride = block_size * num_kv_heads * head_size
+    lib = _lib.load()
+    _lib.check(lib.pe_block_score_value_l2(_p(out), _p(values), _p(block_ids), n_blocks, layout,
+                                           block_stride, num_kv_heads, head_size, block_size,
+                                           _dtype_code(values), _stream(dev)),
+               "block_score_value_l2")
+    return out
+
+
+def evict_select_compact(block_tables: torch.Tensor, seq_lens: torch.Tensor,
+                         num_blocks: torch.Tensor, method: str, cache_budget: int,
+                         block_size: int, topk_blocks: int = -1, *,
+                         victim_override: Optional[torch.Tensor] = None,
+                         drop_victim_score: bool = True, compat_q1: bool = False,
+                         score_layout: int = SCORE_CACHE,
+                         score_table: Optional[torch.Tensor] = None,
+                         score_counts: Optional[torch.Tensor] = None,
+                         score_rows: Optional[torch.Tensor] = None,
+                         value_cache: Optional[torch.Tensor] = None,
+                         compact: bool = True):
+    """One launch per decode step: returns (rmv_idx int32[B], compacted tables int32[B, M-1] or
+    None, zero_slots int64[B] or None)."""
+    dev = _need_gpu(block_tables, seq_lens, num_blocks, victim_override, score_table,
+                    score_counts, score_rows, value_cache)
+    B, M = block_tables.shape
+    for t in (block_tables, seq_lens, num_blocks):
+        if t.dtype != torch.int32 or not t.is_contiguous():
+            raise RuntimeError("evict_select_compact: int32 contiguous tensors expected")
+    m = EVICT_METHODS[method]
+    rmv = torch.empty(B, dtype=torch.int32, device=dev)
+    out_tables = torch.empty((B, max(M - 1, 0)), dtype=torch.int32, device=dev) if compact else None
+    zero = torch.empty(B, dtype=torch.int64, device=dev) if m == 1 else None
+    Hkv = D = 0
+    kv_stride = 0
+    dt = _lib.PE_BF16
+    width = 0
+    if m in (2, 3):
+        if victim_override is None or score_table is not None:
+            if score_table is None or score_counts is None or score_rows is None or value_cache is None:
+                raise RuntimeError("evict_select_compact: local/global need score_table, "
+                                   "score_counts, score_rows and value_cache")
+        if value_cache is not None:
+            _, Hkv, D, bs = value_cache.shape
+            if bs != block_size:
+                raise RuntimeError("evict_select_compact: value_cache block size mismatch")
+            kv_stride = value_cache.stride(0)
+            dt = _dtype_code(value_cache)
+        if score_table is not None:
+            width = score_table.shape[1]
+    lib = _lib.load()
+    _lib.check(lib.pe_evict_select_compact(
+        _p(rmv), _p(out_tables), _p(zero), _p(block_tables), _p(seq_lens), _p(num_blocks),
+        _p(victim_override), B, M, m, cache_budget, block_size, topk_blocks,
+        1 if drop_victim_score else 0, 1 if compat_q1 else 0, score_layout, _p(score_table),
+        _p(score_counts), _p(score_rows), width, _p(value_cache), kv_stride, Hkv, D, dt,
+        _stream(dev)), "evict_select_compact")
+    return rmv, out_tables, zero
+
+
+# -------------------------------------------------------------------------------------- torch.library
+_registered = False
+
+
+def register_torch_ops() -> None:
+    """Register the operators as torch.ops.paged_evict.* with the reference's schemas
+    (csrc/torch_bindings.cpp:27-51,433-450).  Idempotent."""
+    global _registered
+    if _registered:
+        return
+    lib = torch.library.Library("paged_evict", "DEF")
+    lib.define("paged_attention_v1(Tensor! out, Tensor query, Tensor key_cache, Tensor value_cache,"
+               " int num_kv_heads, float scale, Tensor block_tables, Tensor seq_lens,"
+               " int block_size, int max_seq_len, Tensor? alibi_slopes, str kv_cache_dtype,"
+               " float k_scale, float v_scale, int tp_rank, int blocksparse_local_blocks,"
+               " int blocksparse_vert_stride, int blocksparse_block_size,"
+               " int blocksparse_head_sliding_step) -> ()")
+    lib.define("paged_attention_v2(Tensor! out, Tensor! exp_sums, Tensor! max_logits,"
+               " Tensor! tmp_out, Tensor query, Tensor key_cache, Tensor value_cache,"
+               " int num_kv_heads, float scale, Tensor block_tables, Tensor seq_lens,"
+               " int block_size, int max_seq_len, Tensor? alibi_slopes, str kv_cache_dtype,"
+               " float k_scale, float v_scale, int tp_rank, int blocksparse_local_blocks,"
+               " int blocksparse_vert_stride, int blocksparse_block_size,"
+               " int blocksparse_head_sliding_step) -> ()")
+    lib.define("reshape_and_cache(Tensor key, Tensor value, Tensor! key_cache,"
+               " Tensor! value_cache, Tensor slot_mapping, str kv_cache_dtype,"
+               " float k_scale, float v_scale) -> ()")
+    lib.define("copy_blocks(Tensor(a!)[] key_caches, Tensor[](b!) value_caches,"
+               " Tensor block_mapping) -> ()")
+    lib.define("swap_blocks(Tensor src, Tensor! dst, Tensor block_mapping) -> ()")
+    lib.impl("paged_attention_v1", paged_attention_v1, "CUDA")
+    lib.impl("paged_attention_v2", paged_attention_v2, "CUDA")
+    lib.impl("reshape_and_cache", lambda k, v, kc, vc, sm, dt, ks, vs: reshape_and_cache(
+        k, v, kc, vc, sm, dt, ks, vs), "CUDA")
+    lib.impl("copy_blocks", copy_blocks, "CUDA")
+    lib.impl("swap_blocks", swap_blocks, "CompositeExplicitAutograd")
+    register_torch_ops._lib = lib  # keep alive
+    _registered = True
