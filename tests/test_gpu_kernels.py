@@ -39,7 +39,7 @@ def make_cache(nb, H, D, bs, dtype, g, scale=None):
 @pytest.mark.parametrize("H,D,bs", [(8, 128, 16), (12, 64, 16), (2, 80, 16), (8, 128, 32), (4, 64, 8)])
 @pytest.mark.parametrize("pattern", ["random", "prefill", "decode"])
 def test_reshape_and_cache(ops, oracle, dtype, H, D, bs, pattern):
-    g = torch.Generator().manual_seed(hash((H, D, bs, pattern)) % 1000)
+    g = torch.Generator().manual_seed(H * 7 + D + bs + len(pattern))
     nb = 64
     if pattern == "random":
         T = 57
@@ -382,6 +382,11 @@ def test_evict_topk_trace(ops, oracle, method, topk, drop, layout):
                 expect.append(-1)
         assert rmv == expect, (step, rmv, expect)
         assert torch.equal(out.cpu(), oracle.compact_block_tables(bt, expect))
+        if any(e >= len(tables[i]) for i, e in enumerate(expect)):
+            # without dropping the victim's score the list outgrows the table (the reference's
+            # HEAD behaviour) and the index eventually points past it: the trace ends there
+            assert not drop
+            break
         for i in range(B):
             if expect[i] >= 0:
                 free.append(tables[i].pop(expect[i]))

@@ -159,6 +159,9 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void paged_decode_mfma_kernel(
       }
     }
     l_run = l_run * alpha + psum;
+    // slots past seq_len in the last block may hold anything (NaN included): their V is
+    // replaced by zero, as the reference does (attention_kernels.cuh:420-430)
+    const bool tail = (2 * pair + 2) * BS > seq_len;  // wave-uniform
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
       acc[dt] *= alpha;
@@ -167,6 +170,13 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void paged_decode_mfma_kernel(
       for (int j = 0; j < 4; ++j) {
         vf[j] = t.v[0][dt][j];
         vf[4 + j] = t.v[1][dt][j];
+      }
+      if (tail) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int tok = (2 * pair + (j >> 2)) * BS + 4 * g + (j & 3);
+          vf[j] = tok < seq_len ? vf[j] : (T)0.f;
+        }
       }
       acc[dt] = TR::mfma16(vf, pf, acc[dt]);
     }
