@@ -70,7 +70,9 @@ int pe_version(void);
  *   src_index      optional device int32: row of key/value to read for output token i.
  *                  NULL: row i.  src_index_head_stride == 0: one row per token
  *                  (src_index[i]); == 1: one row per (token, head)
- *                  (src_index[i*num_kv_heads + h]) — the prompt-prune gather fused into
+ *                  (src_index[i*num_kv_heads + h]); == 2: one (row, head) pair per
+ *                  (token, head), encoded row*num_kv_heads + head (the compat_q2 output of
+ *                  pe_prompt_token_select) — the prompt-prune gather fused into
  *                  the write (replaces the prune_prompt_inplace + reshape_and_cache pair,
  *                  vllm/attention/backends/torch_cuda_sdpa.py:888-892,1020-1024)
  *   zero_slots     optional device int64[num_zero_slots]: slots whose K and V rows are
@@ -78,7 +80,7 @@ int pe_version(void);
  *                  zero rows the reference appends from TmpCacheSingleton
  *                  (torch_cuda_sdpa.py:919-933,962-976; vllm/worker/tmp_cache_singleton.py)
  *   num_blocks     blocks in the cache, for the range check of slots (a slot beyond the
- *                  cache is skipped and counted in *bad_slots_dev if that is non-NULL)
+ *                  cache is skipped)
  * ---------------------------------------------------------------------------------- */
 int pe_reshape_and_cache(const void* key, const void* value, void* key_cache,
                          void* value_cache, const int64_t* slot_mapping,
@@ -160,11 +162,12 @@ int pe_prompt_keep_index_streaming(int32_t* src_index, const int32_t* cu_q,
  * compat_q2 != 0 lays the index out the way the reference's `middle[mask].view(-1,H,D)`
  * re-packs rows across heads (kvcache_prunner.py:251-252); then each entry is
  * row*num_kv_heads + head of the source (token, head) pair.
+ * total_q = number of key/value rows (= cu_q[num_seqs]).
  * workspace: pe_prompt_token_select_workspace_bytes(total_q, num_kv_heads) bytes. */
 int64_t pe_prompt_token_select_workspace_bytes(int64_t total_q, int num_kv_heads);
 int pe_prompt_token_select(int32_t* src_index, const void* key, const void* value,
                            const int32_t* cu_q, const int32_t* cu_kept, int num_seqs,
-                           int cache_budget, int block_size, int method, int compat_q2,
+                           int64_t total_q, int cache_budget, int block_size, int method, int compat_q2,
                            int64_t key_stride, int64_t value_stride, int num_kv_heads,
                            int head_size, int dtype, void* workspace,
                            int64_t workspace_bytes, void* stream);

@@ -410,3 +410,122 @@ def test_evict_victim_override(ops, oracle):
                                            victim_override=ov.cuda())
     assert rmv.cpu().tolist() == [5, -1, 2]
     assert torch.equal(out.cpu(), oracle.compact_block_tables(tables, [5, -1, 2]))
+
+
+# ------------------------------------------------------------------ prefill attention
+def _cu(lens):
+    return torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32)
+
+
+PREFILL_CASES = [
+    # Hq, Hkv, D, dtype, q_lens, kv_lens (kv < q: prompt pruned before attention)
+    (32, 8, 128, torch.bfloat16, [1024], [768]),
+    (32, 8, 128, torch.bfloat16, [1, 17, 130, 300], [1, 17, 130, 300]),
+    (8, 2, 128, torch.float16, [200, 77, 513], [96, 77, 260]),
+    (12, 12, 64, torch.float16, [333, 64], [333, 64]),
+    (8, 8, 64, torch.bfloat16, [150], [100]),
+    (4, 4, 80, torch.bfloat16, [70, 33], [48, 33]),     # generic path
+    (4, 2, 64, torch.float32, [50], [50]),               # generic path
+]
+
+
+@pytest.mark.parametrize("Hq,Hkv,D,dtype,q_lens,kv_lens", PREFILL_CASES)
+def test_prefill_causal(ops, oracle, Hq, Hkv, D, dtype, q_lens, kv_lens):
+    g = torch.Generator().manual_seed(Hq + D + sum(q_lens))
+    Tq, Tkv = sum(q_lens), sum(kv_lens)
+    q = (torch.rand(Tq, Hq, D, generator=g) * 2 - 1).to(dtype)
+    k = (torch.rand(Tkv, Hkv, D, generator=g) * 2 - 1).to(dtype)
+    v = (torch.rand(Tkv, Hkv, D, generator=g) * 2 - 1).to(dtype)
+    sc = D ** -0.5
+    ref = oracle.prefill_attention(q.float(), k.float(), v.float(), q_lens, kv_lens, sc)
+    out = ops.prefill_causal(q.cuda(), k.cuda(), v.cuda(), _cu(q_lens).cuda(), _cu(kv_lens).cuda(),
+                             max(q_lens), sc)
+    # SDPA on this path is a third-party kernel whose rounding no reference test pins:
+    # tolerance vs an f32 evaluation of the same inputs (bf16: atol 2e-2, rtol 1.6e-2)
+    tol = {torch.bfloat16: (2e-2, 1.6e-2), torch.float16: (3e-3, 1e-2), torch.float32: (1e-4, 1e-4)}[dtype]
+    torch.testing.assert_close(out.cpu().float(), ref, atol=tol[0], rtol=tol[1])
+
+
+def test_prefill_matches_torch_sdpa_top_left(ops):
+    """The mask alignment is the one torch SDPA(is_causal=True) uses for L_q != L_kv."""
+    g = torch.Generator().manual_seed(4)
+    Hq, Hkv, D, Lq, Lkv = 8, 2, 128, 300, 200
+    q = (torch.rand(Lq, Hq, D, generator=g) - 0.5).to(torch.bfloat16)
+    k = (torch.rand(Lkv, Hkv, D, generator=g) - 0.5).to(torch.bfloat16)
+    v = (torch.rand(Lkv, Hkv, D, generator=g) - 0.5).to(torch.bfloat16)
+    kk = k.repeat_interleave(Hq // Hkv, dim=1).float().movedim(0, 1)[None]
+    vv = v.repeat_interleave(Hq // Hkv, dim=1).float().movedim(0, 1)[None]
+    ref = torch.nn.functional.scaled_dot_product_attention(
+        q.float().movedim(0, 1)[None], kk, vv, is_causal=True, scale=D ** -0.5)[0].movedim(0, 1)
+    out = ops.prefill_causal(q.cuda(), k.cuda(), v.cuda(), _cu([Lq]).cuda(), _cu([Lkv]).cuda(), Lq, D ** -0.5)
+    torch.testing.assert_close(out.cpu().float(), ref, atol=2e-2, rtol=1.6e-2)
+
+
+def test_prefill_spike_forces_rescale(ops, oracle):
+    """A key that dominates late in the sequence forces the online-softmax rescale branch."""
+    g = torch.Generator().manual_seed(8)
+    Hq, Hkv, D, L = 4, 1, 128, 400
+    q = (torch.rand(L, Hq, D, generator=g) - 0.5).to(torch.bfloat16)
+    k = (torch.rand(L, Hkv, D, generator=g) - 0.5).to(torch.bfloat16)
+    v = (torch.rand(L, Hkv, D, generator=g) - 0.5).to(torch.bfloat16)
+    k[333, 0] = (q[350, 2].float() * 6).to(torch.bfloat16)
+    ref = oracle.prefill_attention(q.float(), k.float(), v.float(), [L], [L], D ** -0.5)
+    out = ops.prefill_causal(q.cuda(), k.cuda(), v.cuda(), _cu([L]).cuda(), _cu([L]).cuda(), L, D ** -0.5)
+    torch.testing.assert_close(out.cpu().float(), ref, atol=2e-2, rtol=1.6e-2)
+
+
+# ------------------------------------------------------------------ token-level prompt prune
+def test_prompt_token_select_golden(ops, oracle):
+    """Against KVCachePruner.prune_prompt outputs (tie-free f32 inputs): the compat layout
+    reproduces the reference bit for bit; the per-head layout is checked against the oracle."""
+    z = np.load(os.path.join(GOLDEN, "prompt_prune_topk.npz"))
+    n = len([k for k in z.files if k.endswith("_meta")])
+    for c in range(n):
+        L, budget, bs, H, D, m = [int(v) for v in z[f"c{c}_meta"]]
+        method = ["global", "local", "inverse_key_l2"][m]
+        k, v = from_bits(z[f"c{c}_k"], 0), from_bits(z[f"c{c}_v"], 0)
+        n_kept = oracle.pruned_length(L, budget, bs)
+        cu_q, cu_k = _cu([L]).cuda(), _cu([n_kept]).cuda()
+        kd, vd = k.cuda(), v.cuda()
+        idx = ops.prompt_token_select(kd, vd, cu_q, cu_k, n_kept, budget, bs, method, compat_q2=True)
+        pk, pv = ops.prompt_prune_gather(kd, vd, idx, mode=2)
+        assert torch.equal(pk.cpu(), from_bits(z[f"c{c}_pk"], 0)), c
+        assert torch.equal(pv.cpu(), from_bits(z[f"c{c}_pv"], 0)), c
+        idx = ops.prompt_token_select(kd, vd, cu_q, cu_k, n_kept, budget, bs, method)
+        pk, pv = ops.prompt_prune_gather(kd, vd, idx)
+        ek, ev = oracle.prompt_prune(k, v, method, budget, bs)
+        assert torch.equal(pk.cpu(), ek) and torch.equal(pv.cpu(), ev), c
+
+
+@pytest.mark.parametrize("method", ["global", "inverse_key_l2"])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_prompt_token_select_batch_with_ties(ops, oracle, method, dtype):
+    """Batch of prompts in a 16-bit type (many equal scores): ties drop the lowest token first,
+    as the oracle's stable sort does; also checks the fused gather-into-cache form."""
+    g = torch.Generator().manual_seed(12)
+    H, D, bs, budget = 8, 128, 16, 96
+    lens = [40, 300, 97, 1030]
+    kept = [oracle.pruned_length(L, budget, bs) for L in lens]
+    T = sum(lens)
+    k = ((torch.rand(T, H, D, generator=g) * 2 - 1) * D ** -0.5).to(dtype)
+    v = ((torch.rand(T, H, D, generator=g) * 2 - 1) * D ** -0.5).to(dtype)
+    idx = ops.prompt_token_select(k.cuda(), v.cuda(), _cu(lens).cuda(), _cu(kept).cuda(), sum(kept),
+                                  budget, bs, method)
+    pk, pv = ops.prompt_prune_gather(k.cuda(), v.cuda(), idx)
+    off = 0
+    eks, evs = [], []
+    for L in lens:
+        ek, ev = oracle.prompt_prune(k[off:off + L], v[off:off + L], method, budget, bs)
+        eks.append(ek)
+        evs.append(ev)
+        off += L
+    ek, ev = torch.cat(eks), torch.cat(evs)
+    assert torch.equal(pk.cpu(), ek) and torch.equal(pv.cpu(), ev)
+    # fused: gather straight into the paged cache
+    nb = 200
+    kc, vc = make_cache(nb, H, D, bs, dtype, g)
+    kc_d, vc_d = kc.cuda(), vc.cuda()
+    slots = torch.randperm(nb * bs, generator=g)[:sum(kept)].to(torch.int64)
+    oracle.reshape_and_cache(ek, ev, kc, vc, slots)
+    ops.reshape_and_cache(k.cuda(), v.cuda(), kc_d, vc_d, slots.cuda(), src_index=idx)
+    assert torch.equal(kc_d.cpu(), kc) and torch.equal(vc_d.cpu(), vc)

@@ -33,8 +33,8 @@ SIGNATURES = {
                                                c_void_p]),
     "pe_prompt_token_select_workspace_bytes": (c_int64, [c_int64, c_int]),
     "pe_prompt_token_select": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                                       c_int, c_int, c_int, c_int, c_int64, c_int64, c_int, c_int,
-                                       c_int, c_void_p, c_int64, c_void_p]),
+                                       c_int64, c_int, c_int, c_int, c_int, c_int64, c_int64,
+                                       c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
     "pe_block_score_value_l2": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64,
                                         c_int, c_int, c_int, c_int, c_void_p]),
     "pe_evict_select_compact": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -33,7 +33,8 @@ __global__ __launch_bounds__(RC_THREADS) void reshape_and_cache_kernel(
   extern __shared__ __attribute__((aligned(16))) char smem[];
   T* vt = reinterpret_cast<T*>(smem);                       // [head_size][RC_TOKENS]
   int64_t* s_slot = reinterpret_cast<int64_t*>(smem + (size_t)head_size * RC_TOKENS * sizeof(T));
-  int64_t* s_src = s_slot + RC_TOKENS;
+  int64_t* s_src = s_slot + RC_TOKENS;   // element offset of the source V row of (token, head)
+  int64_t* s_srck = s_src + RC_TOKENS;   // same for K
 
   const int h = blockIdx.y;
   const int64_t t0 = (int64_t)blockIdx.x * RC_TOKENS;
@@ -44,13 +45,20 @@ __global__ __launch_bounds__(RC_THREADS) void reshape_and_cache_kernel(
     if (t < num_tokens) {
       slot = slot_mapping[t];
       if (slot >= num_slots) slot = -1;
+      int64_t src_h = h;
       if (src_index == nullptr) {
         src = t;
       } else if (src_head_stride == 0) {
         src = src_index[t];
-      } else {
+      } else if (src_head_stride == 1) {
         src = src_index[t * num_heads + h];
+      } else {  // (row, head) pair
+        const int64_t pr = src_index[t * num_heads + h];
+        src = pr / num_heads;
+        src_h = pr % num_heads;
       }
+      s_srck[tid] = src * key_stride + src_h * head_size;
+      src = src * value_stride + src_h * head_size;
     }
     s_slot[tid] = slot;
     s_src[tid] = src;
@@ -68,14 +76,12 @@ __global__ __launch_bounds__(RC_THREADS) void reshape_and_cache_kernel(
     if (slot < 0) continue;
     const int64_t blk = slot / block_size;
     const int off = (int)(slot % block_size);
-    const u32x4 kv = *reinterpret_cast<const u32x4*>(key + s_src[j] * key_stride +
-                                                     (int64_t)h * head_size + c * X);
+    const u32x4 kv = *reinterpret_cast<const u32x4*>(key + s_srck[j] + c * X);
     union {
       u32x4 v;
       T e[X];
     } u;
-    u.v = *reinterpret_cast<const u32x4*>(value + s_src[j] * value_stride +
-                                          (int64_t)h * head_size + c * X);
+    u.v = *reinterpret_cast<const u32x4*>(value + s_src[j] + c * X);
     T* dst = key_cache + ((blk * num_heads + h) * chunks + c) * (int64_t)block_size * X +
              (int64_t)off * X;
     *reinterpret_cast<u32x4*>(dst) = kv;
@@ -146,11 +152,20 @@ __global__ void prune_gather_kernel(const T* __restrict__ key, const T* __restri
     const int64_t row = i / chunks_per_row;
     const int c = (int)(i % chunks_per_row);
     const int h = c * X / head_size;
-    const int64_t src = src_head_stride == 0 ? src_index[row] : src_index[row * num_heads + h];
+    int64_t src, sc = c;
+    if (src_head_stride == 0) {
+      src = src_index[row];
+    } else if (src_head_stride == 1) {
+      src = src_index[row * num_heads + h];
+    } else {  // (row, head) pair: read the chunk at the same offset inside the source head
+      const int64_t pr = src_index[row * num_heads + h];
+      src = pr / num_heads;
+      sc = (pr % num_heads) * (head_size / X) + (c - h * (head_size / X));
+    }
     *reinterpret_cast<u32x4*>(out_key + row * (int64_t)num_heads * head_size + c * X) =
-        *reinterpret_cast<const u32x4*>(key + src * key_stride + c * X);
+        *reinterpret_cast<const u32x4*>(key + src * key_stride + sc * X);
     *reinterpret_cast<u32x4*>(out_value + row * (int64_t)num_heads * head_size + c * X) =
-        *reinterpret_cast<const u32x4*>(value + src * value_stride + c * X);
+        *reinterpret_cast<const u32x4*>(value + src * value_stride + sc * X);
   }
 }
 
@@ -231,8 +246,8 @@ int pe_reshape_and_cache(const void* key, const void* value, void* key_cache, vo
              "key/value token stride must be a multiple of %d elements", x);
   PE_REQUIRE(((uintptr_t)key | (uintptr_t)value | (uintptr_t)key_cache | (uintptr_t)value_cache) % 16 == 0,
              PE_ERR_INVALID_ARG, "pointers must be 16-byte aligned");
-  PE_REQUIRE(src_index_head_stride == 0 || src_index_head_stride == 1, PE_ERR_INVALID_ARG,
-             "src_index_head_stride must be 0 or 1");
+  PE_REQUIRE(src_index_head_stride >= 0 && src_index_head_stride <= 2, PE_ERR_INVALID_ARG,
+             "src_index_head_stride must be 0, 1 or 2");
   PE_REQUIRE(num_kv_heads <= 65535, PE_ERR_UNSUPPORTED, "too many heads");
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int64_t num_slots = num_blocks * block_size;
@@ -240,7 +255,7 @@ int pe_reshape_and_cache(const void* key, const void* value, void* key_cache, vo
     const int64_t tiles = (num_tokens + RC_TOKENS - 1) / RC_TOKENS;
     PE_REQUIRE(tiles <= 0x7fffffff, PE_ERR_UNSUPPORTED, "too many tokens");
     dim3 grid((unsigned)tiles, (unsigned)num_kv_heads);
-    const size_t lds = (size_t)head_size * RC_TOKENS * es + 2 * RC_TOKENS * sizeof(int64_t);
+    const size_t lds = (size_t)head_size * RC_TOKENS * es + 3 * RC_TOKENS * sizeof(int64_t);
     PE_DISPATCH_ALL(dtype, T,
                     hipLaunchKernelGGL(reshape_and_cache_kernel<T>, grid, dim3(RC_THREADS), lds, st,
                                        (const T*)key, (const T*)value, (T*)key_cache,
@@ -271,8 +286,8 @@ int pe_prompt_prune_gather(const void* key, const void* value, void* out_key, vo
   const int x = 16 / elem_size(dtype);
   PE_REQUIRE(head_size % x == 0 && key_stride % x == 0 && value_stride % x == 0,
              PE_ERR_UNSUPPORTED, "rows must be made of 16-byte chunks");
-  PE_REQUIRE(src_index_head_stride == 0 || src_index_head_stride == 1, PE_ERR_INVALID_ARG,
-             "src_index_head_stride must be 0 or 1");
+  PE_REQUIRE(src_index_head_stride >= 0 && src_index_head_stride <= 2, PE_ERR_INVALID_ARG,
+             "src_index_head_stride must be 0, 1 or 2");
   const int64_t total = n_out * (num_kv_heads * head_size / x);
   int64_t blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;

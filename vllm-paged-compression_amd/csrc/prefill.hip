@@ -1,0 +1,343 @@
+// Varlen causal prefill attention on gfx950 (flash-style, no L_q x L_kv matrix in memory).
+//
+// Mask: query row i of a request attends kv rows 0..min(i, L_kv-1) — the top-left aligned
+// lower triangle that scaled_dot_product_attention(is_causal=True) applies, which is what
+// the reference runs when the prompt was pruned before attention (L_kv < L_q).
+// Grouped KV heads are addressed directly (no repeat_interleave copy).
+//
+// MFMA path (16-bit types, head_size 64/128): a workgroup of 4 waves owns 128 query rows of
+// one (request, head); K/V tiles of 64 tokens are staged global -> registers -> LDS
+// (double-buffered, loads of tile j+1 issued before the math of tile j, written after it).
+//   S^T = K.Q^T   v_mfma_f32_16x16x32: A = K rows from LDS (ds_read_b128, XOR-swizzled
+//                 chunks), B = Q fragments held in registers; a lane ends up with 4 tokens
+//                 x 1 query row, so the row max/sum is a register reduction + 2 shuffles.
+//   O^T += V^T.P^T  A = V^T read with ds_read_b64_tr_b16 from the row-major V tile, B = P
+//                 taken straight from the S^T accumulators (k-slot order chosen to match).
+// The finished O tile goes through LDS so that global stores are whole 16-byte row chunks.
+#include "pe_common.h"
+
+namespace pe {
+
+constexpr int PF_WAVES = 4;
+constexpr int PF_THREADS = PF_WAVES * 64;
+constexpr int PF_BM = 128;  // query rows per workgroup (32 per wave)
+constexpr int PF_BN = 64;   // kv rows per tile
+constexpr float PF_NEG = -1.0e30f;
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+template <int D>
+__device__ __forceinline__ int swz_off(int row, int chunk) {
+  // byte offset of 16-byte chunk `chunk` of row `row` in a [rows][D] 16-bit tile
+  constexpr int CPR = D / 8;
+  const int x = (CPR == 16) ? (row & 15) : ((row >> 1) & 7);
+  return row * (D * 2) + ((chunk ^ x) << 4);
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(PF_THREADS, 2) void prefill_mfma_kernel(
+    T* __restrict__ out, const T* __restrict__ q, const T* __restrict__ k,
+    const T* __restrict__ v, const int32_t* __restrict__ cu_q, const int32_t* __restrict__ cu_kv,
+    int num_heads, int num_kv_heads, int64_t q_stride, int64_t k_stride, int64_t v_stride,
+    int64_t out_stride, float scale_log2e) {
+  using TR = Traits<T>;
+  using vec8 = typename TR::vec8;
+  constexpr int KS = D / 32;
+  constexpr int DT = D / 16;
+  constexpr int CPR = D / 8;                        // 16-byte chunks per row
+  constexpr int TILE_BYTES = PF_BN * D * 2;         // one K or V tile
+  constexpr int CHUNKS_PER_THREAD = PF_BN * CPR / PF_THREADS;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // [buf][K|V][tile]
+  auto k_tile = [&](int buf) { return smem + buf * 2 * TILE_BYTES; };
+  auto v_tile = [&](int buf) { return smem + buf * 2 * TILE_BYTES + TILE_BYTES; };
+
+  const int seq = blockIdx.z;
+  const int head = blockIdx.y;
+  const int kvh = head / (num_heads / num_kv_heads);
+  const int q0 = cu_q[seq], lq = cu_q[seq + 1] - q0;
+  const int kv0 = cu_kv[seq], lkv = cu_kv[seq + 1] - kv0;
+  const int qt = (int)gridDim.x - 1 - (int)blockIdx.x;  // heaviest (last) query tiles first
+  const int m0 = qt * PF_BM;
+  if (m0 >= lq) return;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, c = lane & 15;
+  const int wrow0 = m0 + wave * 32;  // first query row of this wave
+
+  // ---- Q fragments (B operand): lane holds Q[row][32ks + 8g .. +8) for its 2 row tiles ----
+  vec8 qf[2][KS];
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const int row = min(wrow0 + n * 16 + c, lq - 1);
+    const T* qp = q + (int64_t)(q0 + row) * q_stride + (int64_t)head * D + 8 * g;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+      qf[n][ks] = __builtin_bit_cast(vec8, *reinterpret_cast<const u32x4*>(qp + 32 * ks));
+  }
+
+  float m_run[2] = {PF_NEG, PF_NEG};
+  float l_run[2] = {0.f, 0.f};
+  f32x4 acc[DT][2];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) acc[dt][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int kv_end = min(lkv, m0 + PF_BM);  // rows past the last query row are never attended
+  const int n_tiles = (kv_end + PF_BN - 1) / PF_BN;
+
+  u32x4 stage_k[CHUNKS_PER_THREAD], stage_v[CHUNKS_PER_THREAD];
+  auto stage_load = [&](int tile) {
+#pragma unroll
+    for (int i = 0; i < CHUNKS_PER_THREAD; ++i) {
+      const int idx = tid + i * PF_THREADS;
+      const int row = idx / CPR, ch = idx % CPR;
+      const int kvrow = min(tile * PF_BN + row, lkv - 1);
+      stage_k[i] = *reinterpret_cast<const u32x4*>(k + (int64_t)(kv0 + kvrow) * k_stride +
+                                                   (int64_t)kvh * D + ch * 8);
+      stage_v[i] = *reinterpret_cast<const u32x4*>(v + (int64_t)(kv0 + kvrow) * v_stride +
+                                                   (int64_t)kvh * D + ch * 8);
+    }
+  };
+  auto stage_store = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < CHUNKS_PER_THREAD; ++i) {
+      const int idx = tid + i * PF_THREADS;
+      const int row = idx / CPR, ch = idx % CPR;
+      *reinterpret_cast<u32x4*>(k_tile(buf) + swz_off<D>(row, ch)) = stage_k[i];
+      *reinterpret_cast<u32x4*>(v_tile(buf) + swz_off<D>(row, ch)) = stage_v[i];
+    }
+  };
+
+  auto compute = [&](int tile, int buf) {
+    const int n0 = tile * PF_BN;
+    const char* kt = k_tile(buf);
+    const char* vt = v_tile(buf);
+    // ---- S^T = K.Q^T ---------------------------------------------------------------
+    f32x4 s[4][2];
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) {
+      s[sub][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+      s[sub][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const vec8 kf = __builtin_bit_cast(
+            vec8, *reinterpret_cast<const u32x4*>(kt + swz_off<D>(sub * 16 + c, 4 * ks + g)));
+        s[sub][0] = TR::mfma16(kf, qf[0][ks], s[sub][0]);
+        s[sub][1] = TR::mfma16(kf, qf[1][ks], s[sub][1]);
+      }
+    }
+    // ---- scale, mask, online softmax ---------------------------------------------------
+    const bool need_mask = (n0 + PF_BN - 1 > wrow0) || (n0 + PF_BN > lkv);  // wave-uniform
+    vec8 pf[2][2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int qrow = wrow0 + n * 16 + c;
+      const int limit = min(qrow, lkv - 1);  // last kv row this query row may attend
+      float mx = PF_NEG;
+#pragma unroll
+      for (int sub = 0; sub < 4; ++sub) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float x = s[sub][n][r] * scale_log2e;
+          if (need_mask) {
+            const int t = n0 + sub * 16 + 4 * g + r;
+            x = t <= limit ? x : PF_NEG;
+          }
+          s[sub][n][r] = x;
+          mx = fmaxf(mx, x);
+        }
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(m_run[n], mx);
+      const float alpha = __builtin_amdgcn_exp2f(m_run[n] - m_new);
+      m_run[n] = m_new;
+      float psum = 0.f;
+#pragma unroll
+      for (int sub = 0; sub < 4; ++sub) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = __builtin_amdgcn_exp2f(s[sub][n][r] - m_new);
+          psum += p;
+          pf[n][sub >> 1][(sub & 1) * 4 + r] = (T)p;
+        }
+      }
+      l_run[n] = l_run[n] * alpha + psum;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) acc[dt][n] *= alpha;
+    }
+    // ---- O^T += V^T.P^T ------------------------------------------------------------------
+    // transposed read: lane i of each 16-lane group addresses row (4g + i/4), columns
+    // 16dt + 4*(i%4) .. +4 and receives column 16dt+i of the group's 4 rows
+    const int tq = c >> 2, tp = c & 3;
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) {
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const int row_lo = (2 * k2) * 16 + 4 * g + tq;
+        const int row_hi = row_lo + 16;
+        const int ch = 2 * dt + (tp >> 1);
+        const int sub8 = (tp & 1) * 8;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(vt + swz_off<D>(row_lo, ch) + sub8));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(vt + swz_off<D>(row_hi, ch) + sub8));
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        const vec8 vf = __builtin_bit_cast(vec8, both);
+        acc[dt][0] = TR::mfma16(vf, pf[0][k2], acc[dt][0]);
+        acc[dt][1] = TR::mfma16(vf, pf[1][k2], acc[dt][1]);
+      }
+    }
+  };
+
+  // ---- main loop ----------------------------------------------------------------------------
+  if (n_tiles > 0) {
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+    for (int tile = 0; tile < n_tiles; ++tile) {
+      const int buf = tile & 1;
+      if (tile + 1 < n_tiles) stage_load(tile + 1);
+      if (tile * PF_BN <= wrow0 + 31) compute(tile, buf);  // wave-uniform: tile not fully masked
+      if (tile + 1 < n_tiles) stage_store(buf ^ 1);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: normalise, stage the wave's 32 x D tile in LDS, store whole rows -----------
+  T* o_lds = reinterpret_cast<T*>(smem + wave * (32 * D * 2));
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    float l = l_run[n];
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      typename TR::vec4 o4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o4[r] = (T)(acc[dt][n][r] * inv);
+      *reinterpret_cast<typename TR::vec4*>(o_lds + (n * 16 + c) * D + 16 * dt + 4 * g) = o4;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 32 * CPR / 64; ++i) {
+    const int idx = lane + i * 64;
+    const int row = idx / CPR, ch = idx % CPR;
+    const int qrow = wrow0 + row;
+    if (qrow < lq) {
+      *reinterpret_cast<u32x4*>(out + (int64_t)(q0 + qrow) * out_stride + (int64_t)head * D + ch * 8) =
+          *reinterpret_cast<const u32x4*>(o_lds + row * D + ch * 8);
+    }
+  }
+}
+
+// Generic path: one wave per (query row, head); logits of the row in LDS.
+template <typename T>
+__global__ __launch_bounds__(64) void prefill_generic_kernel(
+    T* __restrict__ out, const T* __restrict__ q, const T* __restrict__ k,
+    const T* __restrict__ v, const int32_t* __restrict__ cu_q, const int32_t* __restrict__ cu_kv,
+    int num_heads, int num_kv_heads, int head_size, int64_t q_stride, int64_t k_stride,
+    int64_t v_stride, int64_t out_stride, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* qs = reinterpret_cast<float*>(smem);
+  float* logits = qs + ((head_size + 3) & ~3);
+  const int seq = blockIdx.z, head = blockIdx.y, i = blockIdx.x;
+  const int kvh = head / (num_heads / num_kv_heads);
+  const int q0 = cu_q[seq], lq = cu_q[seq + 1] - q0;
+  const int kv0 = cu_kv[seq], lkv = cu_kv[seq + 1] - kv0;
+  if (i >= lq) return;
+  const int lane = threadIdx.x;
+  const int n = min(i + 1, lkv);
+  const T* qp = q + (int64_t)(q0 + i) * q_stride + (int64_t)head * head_size;
+  for (int d = lane; d < head_size; d += 64) qs[d] = to_f32(qp[d]);
+  __syncthreads();
+  float mx = PF_NEG;
+  for (int t = lane; t < n; t += 64) {
+    const T* kp = k + (int64_t)(kv0 + t) * k_stride + (int64_t)kvh * head_size;
+    float dot = 0.f;
+    for (int d = 0; d < head_size; ++d) dot += qs[d] * to_f32(kp[d]);
+    dot *= scale;
+    logits[t] = dot;
+    mx = fmaxf(mx, dot);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int t = lane; t < n; t += 64) {
+    const float e = __expf(logits[t] - mx);
+    logits[t] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  __syncthreads();
+  const float inv = sum > 0.f ? 1.f / sum : 0.f;
+  T* op = out + (int64_t)(q0 + i) * out_stride + (int64_t)head * head_size;
+  for (int d = lane; d < head_size; d += 64) {
+    float a = 0.f;
+    for (int t = 0; t < n; ++t)
+      a += logits[t] * to_f32(v[(int64_t)(kv0 + t) * v_stride + (int64_t)kvh * head_size + d]);
+    op[d] = from_f32<T>(a * inv);
+  }
+}
+
+}  // namespace pe
+
+extern "C" int pe_prefill_causal(void* out, const void* q, const void* k, const void* v,
+                                 const int32_t* cu_q, const int32_t* cu_kv, int num_seqs,
+                                 int max_q_len, int num_heads, int num_kv_heads, int head_size,
+                                 int64_t q_stride, int64_t k_stride, int64_t v_stride,
+                                 int64_t out_stride, float scale, int dtype, void* stream) {
+  using namespace pe;
+  PE_REQUIRE(num_seqs >= 0 && max_q_len >= 0, PE_ERR_INVALID_ARG, "prefill: negative size");
+  if (num_seqs == 0 || max_q_len == 0) return PE_OK;
+  PE_REQUIRE(out && q && k && v && cu_q && cu_kv, PE_ERR_INVALID_ARG, "prefill: null pointer");
+  PE_REQUIRE(num_heads > 0 && num_kv_heads > 0 && num_heads % num_kv_heads == 0 && head_size > 0,
+             PE_ERR_INVALID_ARG, "prefill: bad head layout");
+  PE_REQUIRE(num_seqs <= 65535 && num_heads <= 65535, PE_ERR_UNSUPPORTED, "prefill: grid too large");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool mfma = (dtype == PE_BF16 || dtype == PE_F16) && (head_size == 64 || head_size == 128) &&
+                    q_stride % 8 == 0 && k_stride % 8 == 0 && v_stride % 8 == 0 &&
+                    out_stride % 8 == 0 &&
+                    (((uintptr_t)out | (uintptr_t)q | (uintptr_t)k | (uintptr_t)v) % 16 == 0);
+  if (mfma) {
+    const int q_tiles = (max_q_len + PF_BM - 1) / PF_BM;
+    dim3 grid((unsigned)q_tiles, (unsigned)num_heads, (unsigned)num_seqs);
+    const float sl2 = scale * 1.4426950408889634f;
+#define PE_LAUNCH_PF(T, HS)                                                                        \
+  do {                                                                                             \
+    const size_t lds = 4 * (size_t)PF_BN * HS * 2;                                                 \
+    hipLaunchKernelGGL((prefill_mfma_kernel<T, HS>), grid, dim3(PF_THREADS), lds, st, (T*)out,      \
+                       (const T*)q, (const T*)k, (const T*)v, cu_q, cu_kv, num_heads, num_kv_heads, \
+                       q_stride, k_stride, v_stride, out_stride, sl2);                             \
+  } while (0)
+    PE_DISPATCH_16(dtype, T, {
+      if (head_size == 64) PE_LAUNCH_PF(T, 64);
+      else PE_LAUNCH_PF(T, 128);
+    });
+#undef PE_LAUNCH_PF
+    return check_launch("prefill_causal");
+  }
+  const size_t lds = (size_t)(((head_size + 3) & ~3) + max_q_len) * 4;
+  PE_REQUIRE(lds <= 160 * 1024, PE_ERR_UNSUPPORTED,
+             "generic prefill path keeps a row of logits in LDS: max_q_len %d too long", max_q_len);
+  dim3 grid((unsigned)max_q_len, (unsigned)num_heads, (unsigned)num_seqs);
+#define PE_LAUNCH_PFG(T)                                                                          \
+  do {                                                                                            \
+    if (lds > 64 * 1024)                                                                          \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&prefill_generic_kernel<T>),        \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);            \
+    hipLaunchKernelGGL(prefill_generic_kernel<T>, grid, dim3(64), lds, st, (T*)out, (const T*)q,   \
+                       (const T*)k, (const T*)v, cu_q, cu_kv, num_heads, num_kv_heads, head_size,  \
+                       q_stride, k_stride, v_stride, out_stride, scale);                          \
+  } while (0)
+  PE_DISPATCH_ALL(dtype, T, PE_LAUNCH_PFG(T));
+#undef PE_LAUNCH_PFG
+  return check_launch("prefill_generic");
+}

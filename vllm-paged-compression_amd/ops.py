@@ -84,11 +84,12 @@ def _check_kv_cache_args(kv_cache_dtype: str, k_scale: float, v_scale: float) ->
 def reshape_and_cache(key: torch.Tensor, value: torch.Tensor, key_cache: torch.Tensor,
                       value_cache: torch.Tensor, slot_mapping: torch.Tensor,
                       kv_cache_dtype: str = "auto", k_scale: float = 1.0, v_scale: float = 1.0,
-                      *, src_index: Optional[torch.Tensor] = None,
+                      *, src_index: Optional[torch.Tensor] = None, src_pairs: bool = False,
                       zero_slots: Optional[torch.Tensor] = None) -> None:
     """key/value [T, H_kv, D]; key_cache [nb, H_kv, D/x, bs, x]; value_cache [nb, H_kv, D, bs];
     slot_mapping int64[T].  ``src_index`` (int32 [T] or [T, H_kv]) fuses a row gather into the
-    write; ``zero_slots`` (int64 [n]) zeroes those slots after the write."""
+    write (``src_pairs``: [T, H_kv] entries are row*H_kv+head pairs); ``zero_slots``
+    (int64 [n]) zeroes those slots after the write."""
     _check_kv_cache_args(kv_cache_dtype, k_scale, v_scale)
     dev = _need_gpu(key, value, key_cache, value_cache, slot_mapping, src_index, zero_slots)
     if key_cache.dim() != 5 or value_cache.dim() != 4:
@@ -113,7 +114,7 @@ def reshape_and_cache(key: torch.Tensor, value: torch.Tensor, key_cache: torch.T
         if src_index.dim() == 2:
             if src_index.shape != (T, H):
                 raise RuntimeError("reshape_and_cache: src_index must be [T] or [T, H_kv]")
-            head_stride = 1
+            head_stride = 2 if src_pairs else 1
         elif src_index.numel() != T:
             raise RuntimeError("reshape_and_cache: src_index must be [T] or [T, H_kv]")
     elif key.shape[0] < T or value.shape[0] < T:
@@ -286,7 +287,7 @@ def prompt_token_select(key: torch.Tensor, value: torch.Tensor, cu_q: torch.Tens
     need = lib.pe_prompt_token_select_workspace_bytes(T, H)
     ws = _workspace(dev, need, "select")
     _lib.check(lib.pe_prompt_token_select(
-        _p(idx), _p(key), _p(value), _p(cu_q), _p(cu_kept), cu_q.numel() - 1, cache_budget,
+        _p(idx), _p(key), _p(value), _p(cu_q), _p(cu_kept), cu_q.numel() - 1, T, cache_budget,
         block_size, EVICT_METHODS[method], 1 if compat_q2 else 0, key.stride(0), value.stride(0),
         H, D, _dtype_code(key), _p(ws), 0 if ws is None else ws.numel(), _stream(dev)),
         "prompt_token_select")
