@@ -208,8 +208,11 @@ int pe_block_score_value_l2(float* scores_out, const void* values,
  *     drop_victim_score != 0 the victim's entry is deleted from the list so that the
  *     list keeps tracking the table (the call the reference leaves commented out, :1546).
  * Outputs: rmv_idx_out[b] = victim index or -1; out_tables[b] = row b without that
- * column, width max_blocks-1 (intended semantics; compat_q1 != 0 reproduces the
- * reference's in-loop slice, :1583, and then runs the rows serially);
+ * column, out_width entries per row (zero-filled past the row's end).  The reference's
+ * shape is out_width = max_blocks-1, which cuts the last block off a row that evicts nothing
+ * but is max_blocks long; a caller that knows the row lengths passes the longest surviving
+ * row instead.  compat_q1 != 0 reproduces the reference's in-loop slice (:1583), needs
+ * out_width == max_blocks-1 and runs the rows serially;
  * zero_slots_out[b] = slot to zero or -1 (may be NULL unless streamingLLM-1).
  * out_tables may be NULL to skip compaction.
  * ---------------------------------------------------------------------------------- */
@@ -217,7 +220,7 @@ int pe_evict_select_compact(int32_t* rmv_idx_out, int32_t* out_tables,
                             int64_t* zero_slots_out, const int32_t* block_tables,
                             const int32_t* seq_lens, const int32_t* num_blocks,
                             const int32_t* victim_override, int batch, int max_blocks,
-                            int method, int cache_budget, int block_size, int topk_blocks,
+                            int out_width, int method, int cache_budget, int block_size, int topk_blocks,
                             int drop_victim_score, int compat_q1, int score_layout,
                             float* score_table, int32_t* score_counts,
                             const int32_t* score_rows, int score_table_width,

@@ -307,26 +307,31 @@ float orc_block_score(const void* values, int block_size, int num_kv_heads,
  * Block-table compaction, intended semantics of
  * TorchCUDASDPABackendImpl._create_updated_block_tables,
  * vllm/attention/backends/torch_cuda_sdpa.py:1562-1586: row b loses column
- * rmv_idx[b] (rmv_idx[b] < 0: nothing removed, row truncated to width-1), the
- * rest shifts left; output width is max_blocks-1.
+ * rmv_idx[b] (rmv_idx[b] < 0: nothing removed), the rest shifts left.  The reference's
+ * output width is max_blocks-1, which silently drops the last block of a row that
+ * evicts nothing but is max_blocks long; out_width lets the caller keep such rows
+ * whole (out_width = longest surviving row; entries past a row's end are 0).
  * compat_q1 != 0 reproduces the reference's loop exactly, including the slice
  * taken inside the loop (:1583), which for rows b >= 1 of a full-width table
  * drops the last block and repeats the one before it.
  */
 void orc_compact_block_tables(const int32_t* tables, const int32_t* rmv_idx,
                               int32_t* out, int batch, int max_blocks,
-                              int compat_q1) {
-  const int w = max_blocks - 1;
-  if (w <= 0) return;
+                              int out_width, int compat_q1) {
   if (!compat_q1) {
     for (int b = 0; b < batch; ++b) {
       const int32_t* row = tables + (int64_t)b * max_blocks;
-      int32_t* o = out + (int64_t)b * w;
+      int32_t* o = out + (int64_t)b * out_width;
       const int r = rmv_idx[b];
-      for (int j = 0; j < w; ++j) o[j] = (r >= 0 && j >= r) ? row[j + 1] : row[j];
+      for (int j = 0; j < out_width; ++j) {
+        const int src = (r >= 0 && j >= r) ? j + 1 : j;
+        o[j] = src < max_blocks ? row[src] : 0;
+      }
     }
     return;
   }
+  const int w = max_blocks - 1; /* the reference's shape; out_width must equal it */
+  if (w <= 0 || out_width != w) return;
   /* literal walk of the reference loop on a working copy whose width shrinks
      after the first iteration */
   int32_t* work = (int32_t*)malloc(sizeof(int32_t) * (size_t)batch * (size_t)max_blocks);

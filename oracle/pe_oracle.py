@@ -127,14 +127,23 @@ def block_score(values: torch.Tensor, block_size: int, num_kv_heads: int, head_s
                                        ctypes.c_int(layout), ctypes.c_int(_DT[values.dtype])))
 
 
-def compact_block_tables(tables: torch.Tensor, rmv_idx: Sequence[int], compat_q1: bool = False):
+def compact_block_tables(tables: torch.Tensor, rmv_idx: Sequence[int], compat_q1: bool = False,
+                         out_width: Optional[int] = None):
+    """out_width None: the reference's shape [B, M-1]."""
     tables = tables.to(torch.int32).contiguous()
     B, M = tables.shape
+    w = max(M - 1, 0) if out_width is None else out_width
     rmv = torch.tensor(list(rmv_idx), dtype=torch.int32)
-    out = torch.zeros((B, max(M - 1, 0)), dtype=torch.int32)
+    out = torch.zeros((B, w), dtype=torch.int32)
     lib().orc_compact_block_tables(_p(tables), _p(rmv), _p(out), ctypes.c_int(B),
-                                   ctypes.c_int(M), ctypes.c_int(1 if compat_q1 else 0))
+                                   ctypes.c_int(M), ctypes.c_int(w),
+                                   ctypes.c_int(1 if compat_q1 else 0))
     return out
+
+
+def surviving_width(table_lens: Sequence[int], rmv_idx: Sequence[int]) -> int:
+    """Longest block-table row after this step's removals."""
+    return max(n - (1 if r >= 0 else 0) for n, r in zip(table_lens, rmv_idx))
 
 
 def prefill_attention(query, key, value, q_lens: Sequence[int], kv_lens: Sequence[int], scale):

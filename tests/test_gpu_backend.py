@@ -1,0 +1,212 @@
+"""End-to-end parity of the backend (metadata builder -> impl.forward over several layers ->
+get_rmv_block_idx -> scheduler commit) against a CPU walk of the reference semantics built
+from the oracle's pieces, on the same scheduler state: block tables and eviction indices must
+be identical every step, attention outputs within the kernel-test tolerance."""
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BS = 16
+
+
+def _mk_inputs(T, Hq, Hkv, D, g):
+    sc = D ** -0.5
+    q = ((torch.rand(T, Hq * D, generator=g) * 2 - 1) * sc * 3).to(torch.bfloat16)
+    k = ((torch.rand(T, Hkv * D, generator=g) * 2 - 1) * sc * 3).to(torch.bfloat16)
+    v = ((torch.rand(T, Hkv * D, generator=g) * 2 - 1)).to(torch.bfloat16)
+    return q, k, v
+
+
+def _builder(cfg, inter):
+    from vllm_paged_compression_amd.backend import PagedEvictBackend
+    from vllm_paged_compression_amd.config import CacheConfigView
+    runner = SimpleNamespace(device=torch.device("cuda:0"),
+                             cache_config=CacheConfigView(BS, cfg), pin_memory=False)
+    ib = SimpleNamespace(runner=runner, sliding_window=None, block_size=BS,
+                         chunked_prefill_enabled=False, inter_data_list=inter)
+    return PagedEvictBackend.make_metadata_builder(ib)
+
+
+@pytest.mark.parametrize("method", ["streamingLLM", "streamingLLM-1", "global", "local"])
+@pytest.mark.parametrize("disable_evict_prefill", [True, False])
+def test_backend_generation_trace(oracle, method, disable_evict_prefill):
+    from vllm_paged_compression_amd.backend import PagedEvictBackend
+    from vllm_paged_compression_amd.block_table import EvictBlockSpaceManager, EvictionScheduler
+    from vllm_paged_compression_amd.config import CacheConfigView, PagedEvictConfig
+
+    g = torch.Generator().manual_seed(31)
+    Hq, Hkv, D, L_layers, nb = 8, 2, 128, 2, 96
+    budget, n_decode = 128, 40
+    cfg = PagedEvictConfig(disable_evict_prefill, "budget", method, budget, 3)
+    cache_cfg = CacheConfigView(BS, cfg)
+    impl_cls = PagedEvictBackend.get_impl_cls()
+    impls = [impl_cls(Hq, D, D ** -0.5, Hkv, None, None, "auto", None, None, cache_config=cache_cfg,
+                      prefix=f"model.layers.{i}.self_attn.attn") for i in range(L_layers)]
+    shape = PagedEvictBackend.get_kv_cache_shape(nb, BS, Hkv, D)
+    kv_gpu = [torch.zeros(shape, dtype=torch.bfloat16, device="cuda") for _ in range(L_layers)]
+    x = 8
+    kc_cpu = [torch.zeros(nb, Hkv, D // x, BS, x, dtype=torch.bfloat16) for _ in range(L_layers)]
+    vc_cpu = [torch.zeros(nb, Hkv, D, BS, dtype=torch.bfloat16) for _ in range(L_layers)]
+
+    sched = EvictionScheduler(EvictBlockSpaceManager(BS, nb, cfg, watermark=0.0))
+    prompts = {"r0": 200, "r1": 130, "r2": 90}
+    seq_of = {"r0": 0, "r1": 1, "r2": 2}
+    for rid, n in prompts.items():
+        assert sched.block_manager.can_allocate(n) == "OK"
+        sched.add_request(rid, seq_of[rid], n)
+    bm = sched.block_manager
+    # expected allocation: pruned prompts (page_evict_kv_util.py:6-36)
+    for rid, n in prompts.items():
+        nblk, ntok = oracle.num_required_blocks_after_prune(n, budget, BS)
+        assert len(bm.get_block_table(seq_of[rid])) == nblk and bm.get_seq_kv_len(seq_of[rid]) == ntok
+
+    # ----------------------------------------------------------------- prefill step
+    inter = []
+    for rid, n in prompts.items():
+        sid = seq_of[rid]
+        inter.append(SimpleNamespace(
+            request_id=rid, is_prompt=True, block_tables={sid: list(bm.get_block_table(sid))},
+            seq_kv_lens={sid: bm.get_seq_kv_len(sid)}, seq_ids=[sid], input_tokens=[[0] * n],
+            orig_seq_lens=[n], seq_lens=[n], query_lens=[n], context_lens=[0]))
+    lens = list(prompts.values())
+    meta = _builder(cfg, inter).build(lens, lens, -1, len(lens))
+    slot_expect = []
+    for it in inter:
+        sid = it.seq_ids[0]
+        slot_expect += oracle.prompt_slot_mapping(it.block_tables[sid], it.seq_lens[0], BS)
+    assert meta.slot_mapping.cpu().tolist() == slot_expect
+    assert meta.seq_kv_lens == [oracle.pruned_length(n, budget, BS) for n in lens]
+    # host-side score model for global/local (per layer-0 only; decisions are per step)
+    scores = {}
+    T = sum(lens)
+    for li in range(L_layers):
+        q, k, v = _mk_inputs(T, Hq, Hkv, D, g)
+        out = impls[li].forward(q.cuda(), k.cuda(), v.cuda(), kv_gpu[li], meta)
+        k3, v3, q3 = k.view(T, Hkv, D), v.view(T, Hkv, D), q.view(T, Hq, D)
+        pk, pv, off = [], [], 0
+        for n in lens:
+            a, b = oracle.prompt_prune(k3[off:off + n], v3[off:off + n], method, budget, BS)
+            pk.append(a)
+            pv.append(b)
+            off += n
+        kept = [t.shape[0] for t in pk]
+        pk_all, pv_all = torch.cat(pk), torch.cat(pv)
+        if disable_evict_prefill:
+            ref = oracle.prefill_attention(q3.float(), k3.float(), v3.float(), lens, lens, D ** -0.5)
+        else:
+            ref = oracle.prefill_attention(q3.float(), pk_all.float(), pv_all.float(), lens, kept, D ** -0.5)
+        torch.testing.assert_close(out.cpu().float().view(T, Hq, D), ref, atol=2e-2, rtol=1.6e-2)
+        oracle.reshape_and_cache(pk_all, pv_all, kc_cpu[li], vc_cpu[li], torch.tensor(slot_expect))
+        kc_g, vc_g = kv_gpu[li][0].view_as(kc_cpu[li]), kv_gpu[li][1].view_as(vc_cpu[li])
+        assert torch.equal(kc_g.cpu(), kc_cpu[li]) and torch.equal(vc_g.cpu(), vc_cpu[li])
+        if li == 0 and method in ("global", "local"):
+            for i, t in enumerate(pv):
+                scores[i] = [oracle.block_score(t[b * BS:(b + 1) * BS].contiguous(), BS, Hkv, D, 0)
+                             for b in range(t.shape[0] // BS)]
+    assert impls[0].get_rmv_block_idx() == {}
+
+    # ----------------------------------------------------------------- decode steps
+    seq_len = dict(zip(prompts.keys(), lens))
+    n_evictions = 0
+    for step in range(n_decode):
+        tables, kv_lens = sched.schedule_decode(list(prompts.keys()))
+        inter, logical, kv_adj = [], [], []
+        for rid in prompts:
+            sid = seq_of[rid]
+            seq_len[rid] += 1
+            L = seq_len[rid]
+            kvl = kv_lens[sid]
+            if oracle.decode_trigger(L, budget, BS):   # model_runner.py:538-543
+                kvl -= BS
+            logical.append(L)
+            kv_adj.append(kvl)
+            inter.append(SimpleNamespace(
+                request_id=rid, is_prompt=False, block_tables={sid: list(tables[sid])},
+                seq_kv_lens={sid: kvl}, seq_ids=[sid], input_tokens=[[0]], orig_seq_lens=[L],
+                seq_lens=[L], query_lens=[1], context_lens=[kv_lens[sid] - 1]))
+        meta = _builder(cfg, inter).build(logical, [1] * 3, -1, 3)
+        tbls = [list(tables[seq_of[r]]) for r in prompts]
+        slots = [oracle.decode_slot(t, kv_lens[seq_of[r]] - 1, BS) for t, r in zip(tbls, prompts)]
+        assert meta.slot_mapping.cpu().tolist() == slots
+        M = max(len(t) for t in tbls)
+        bt = torch.zeros((3, M), dtype=torch.int32)
+        for i, t in enumerate(tbls):
+            bt[i, :len(t)] = torch.tensor(t)
+        # expected decision
+        zero_slots = []
+        if method in ("streamingLLM", "streamingLLM-1"):
+            rmv, zero_slots = oracle.decode_streaming(logical, tbls, budget, BS, method)
+        else:
+            rmv = []
+            for i, L in enumerate(logical):
+                if oracle.decode_trigger(L, budget, BS):
+                    new = oracle.block_score(vc_cpu[0][tbls[i][-1]], BS, Hkv, D, 1)
+                    rmv.append(oracle.decode_topk_victim(scores[i], new, method, 3, True))
+                else:
+                    rmv.append(-1)
+        use_tables = bt
+        if any(r >= 0 for r in rmv):
+            use_tables = oracle.compact_block_tables(
+                bt, rmv, out_width=oracle.surviving_width([len(t) for t in tbls], rmv))
+        for li in range(L_layers):
+            q, k, v = _mk_inputs(3, Hq, Hkv, D, g)
+            out = impls[li].forward(q.cuda(), k.cuda(), v.cuda(), kv_gpu[li], meta)
+            oracle.reshape_and_cache(k.view(3, Hkv, D), v.view(3, Hkv, D), kc_cpu[li], vc_cpu[li],
+                                     torch.tensor(slots))
+            if zero_slots:
+                z = torch.zeros(len(zero_slots), Hkv, D, dtype=torch.bfloat16)
+                oracle.reshape_and_cache(z, z, kc_cpu[li], vc_cpu[li], torch.tensor(zero_slots))
+            assert torch.equal(kv_gpu[li][0].view_as(kc_cpu[li]).cpu(), kc_cpu[li]), (step, li)
+            assert torch.equal(kv_gpu[li][1].view_as(vc_cpu[li]).cpu(), vc_cpu[li]), (step, li)
+            ref = oracle.paged_attention(q.view(3, Hq, D), kc_cpu[li], vc_cpu[li], use_tables,
+                                         torch.tensor(kv_adj, dtype=torch.int32), D ** -0.5)
+            torch.testing.assert_close(out.cpu().float().view(3, Hq, D), ref.float(), atol=2e-3, rtol=1.6e-2,
+                                       msg=lambda m: f"step {step} layer {li} rmv {rmv} kv {kv_adj} L {logical}: {m}")
+        got = impls[0].get_rmv_block_idx()
+        expect = {i: (rid, r) for i, (rid, r) in enumerate(zip(prompts, rmv)) if r >= 0}
+        assert got == expect, (step, got, expect)
+        n_evictions += len(expect)
+        sched.commit(got)
+        for i, rid in enumerate(prompts):
+            if rmv[i] >= 0:
+                del tbls[i][rmv[i]]
+            assert bm.get_block_table(seq_of[rid]) == tbls[i]
+    assert n_evictions >= 3
+    # caches identical at the end (KV writes + zeroed slots are byte-exact)
+    for li in range(L_layers):
+        assert torch.equal(kv_gpu[li][0].view_as(kc_cpu[li]).cpu(), kc_cpu[li])
+        assert torch.equal(kv_gpu[li][1].view_as(vc_cpu[li]).cpu(), vc_cpu[li])
+    # steady state: every sequence holds between budget and budget + block tokens
+    for rid in prompts:
+        assert budget <= bm.get_seq_kv_len(seq_of[rid]) <= budget + BS or seq_len[rid] <= budget + BS
+
+
+def test_backend_no_eviction_plain_path():
+    """Eviction off: plain paged attention (prefill + decode) through the same backend."""
+    from vllm_paged_compression_amd.backend import PagedEvictBackend
+    from vllm_paged_compression_amd.config import CacheConfigView
+    from oracle import pe_oracle as oracle
+    g = torch.Generator().manual_seed(3)
+    Hq, Hkv, D, nb = 12, 12, 64, 32
+    impl = PagedEvictBackend.get_impl_cls()(Hq, D, D ** -0.5, Hkv, None, None, "auto", None, None,
+                                            cache_config=CacheConfigView(BS, None), prefix="")
+    kv = torch.zeros(PagedEvictBackend.get_kv_cache_shape(nb, BS, Hkv, D), dtype=torch.float16, device="cuda")
+    n = 70
+    table = list(range(5, 10))
+    inter = [SimpleNamespace(request_id="a", is_prompt=True, block_tables={0: table}, seq_kv_lens={0: n},
+                             seq_ids=[0], input_tokens=[[0] * n], orig_seq_lens=[n], seq_lens=[n],
+                             query_lens=[n], context_lens=[0])]
+    meta = _builder(None, inter).build([n], [n], -1, 1)
+    q = (torch.rand(n, Hq * D, generator=g) - 0.5).half()
+    k = (torch.rand(n, Hkv * D, generator=g) - 0.5).half()
+    v = (torch.rand(n, Hkv * D, generator=g) - 0.5).half()
+    out = impl.forward(q.cuda(), k.cuda(), v.cuda(), kv, meta)
+    ref = oracle.prefill_attention(q.view(n, Hq, D).float(), k.view(n, Hkv, D).float(),
+                                   v.view(n, Hkv, D).float(), [n], [n], D ** -0.5)
+    torch.testing.assert_close(out.cpu().float().view(n, Hq, D), ref, atol=3e-3, rtol=1e-2)
+    # profiling run: empty cache tensor, output still produced
+    out2 = impl.forward(q.cuda(), k.cuda(), v.cuda(), torch.empty(0, device="cuda", dtype=torch.float16), meta)
+    torch.testing.assert_close(out2, out)

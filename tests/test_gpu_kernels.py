@@ -242,8 +242,8 @@ def test_paged_decode_errors(ops):
     out = torch.empty_like(q)
     with pytest.raises(NotImplementedError):
         ops.paged_attention_v1(out, q, kc, vc, 2, 1.0, bt, lens, 16, 1, None, "fp8", 1.0, 1.0)
-    with pytest.raises(RuntimeError):  # table too narrow for max_seq_len
-        ops.paged_attention_v1(out, q, kc, vc, 2, 1.0, bt, lens, 16, 100, None, "auto", 1.0, 1.0)
+    # max_seq_len larger than the table addresses (the logical length under eviction) is fine
+    ops.paged_attention_v1(out, q, kc, vc, 2, 1.0, bt, lens, 16, 100, None, "auto", 1.0, 1.0)
     with pytest.raises(RuntimeError):  # CPU tensors
         ops.paged_attention_v1(out.cpu(), q.cpu(), kc.cpu(), vc.cpu(), 2, 1.0, bt.cpu(), lens.cpu(), 16, 1,
                                None, "auto", 1.0, 1.0)

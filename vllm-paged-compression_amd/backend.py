@@ -1,0 +1,691 @@
+"""PagedEvictBackend — the attention backend of the paged-KV-eviction path on MI355X.
+
+Drop-in for the reference's ``TorchCUDASDPABackend`` family
+(vllm/attention/backends/torch_cuda_sdpa.py:43-1586) behind the ``vllm.attention`` backend
+API (vllm/attention/backends/abstract.py:32-258): same static methods, the same metadata
+fields (``seq_kv_lens``, ``seq_kv_lens_tensor``, ``reqid_mapping_blocktables`` included, so the
+driver->worker broadcast of metadata kwargs round-trips), the same builder entry points and
+``AttentionImpl.forward`` / ``get_rmv_block_idx`` contract.  When vLLM is importable the
+classes subclass its abstract bases; otherwise they are duck-typed.
+
+What differs from the reference by design:
+  * prefill, decode, KV write, prompt prune, block scoring, victim choice and block-table
+    compaction are HIP kernels (one launch each) instead of eager torch + Python loops;
+  * the decode-step eviction decision is taken once per step (first layer that runs) and
+    shared by all layers through the step's metadata object; ``CompatFlags.per_layer_decision``
+    restores the reference's one-decision-per-layer behaviour;
+  * evicted slots are zeroed by the KV-write kernel (``zero_slots``) instead of appending zero
+    rows from a TmpCacheSingleton scratch tensor (vllm/worker/tmp_cache_singleton.py).
+"""
+from __future__ import annotations
+
+import random
+from dataclasses import dataclass, field, fields
+from itertools import accumulate
+from typing import Any, Dict, List, Optional, Tuple, Type
+
+import torch
+
+from . import ops, parallel
+from .block_l2norm_manager import BlockL2NormManager
+from .config import CompatFlags, PagedEvictConfig
+from .paged_attn import PagedAttention
+from .pruner import KVCachePruner
+
+try:  # pragma: no cover - exercised only inside a vLLM installation
+    from vllm.attention.backends.abstract import (AttentionBackend as _BackendBase,
+                                                  AttentionImpl as _ImplBase,
+                                                  AttentionMetadata as _MetadataBase,
+                                                  AttentionMetadataBuilder as _BuilderBase)
+    from vllm.attention.backends.utils import CommonAttentionState as _StateCls
+    _HAVE_VLLM = True
+except Exception:  # vLLM absent: plain base classes
+    _BackendBase = _ImplBase = _BuilderBase = object
+    _MetadataBase = object
+    _StateCls = None
+    _HAVE_VLLM = False
+
+PAD_SLOT_ID = -1
+
+
+class AttentionType:
+    DECODER = "decoder"
+    ENCODER = "encoder"
+    ENCODER_ONLY = "encoder_only"
+    ENCODER_DECODER = "encoder_decoder"
+
+
+class PagedEvictBackend(_BackendBase):
+
+    @staticmethod
+    def get_name() -> str:
+        return "PAGED_EVICT_HIP"
+
+    @staticmethod
+    def get_impl_cls() -> Type["PagedEvictImpl"]:
+        return PagedEvictImpl
+
+    @staticmethod
+    def get_metadata_cls() -> Type["PagedEvictMetadata"]:
+        return PagedEvictMetadata
+
+    @staticmethod
+    def get_state_cls():
+        if _StateCls is None:
+            raise RuntimeError("CommonAttentionState needs a vLLM installation")
+        return _StateCls
+
+    @staticmethod
+    def get_builder_cls() -> Type["PagedEvictMetadataBuilder"]:
+        return PagedEvictMetadataBuilder
+
+    @classmethod
+    def make_metadata(cls, *args, **kwargs) -> "PagedEvictMetadata":
+        return cls.get_metadata_cls()(*args, **kwargs)
+
+    @classmethod
+    def make_metadata_builder(cls, *args, **kwargs) -> "PagedEvictMetadataBuilder":
+        return cls.get_builder_cls()(*args, **kwargs)
+
+    @staticmethod
+    def get_kv_cache_shape(num_blocks: int, block_size: int, num_kv_heads: int,
+                           head_size: int) -> Tuple[int, ...]:
+        return PagedAttention.get_kv_cache_shape(num_blocks, block_size, num_kv_heads, head_size)
+
+    @staticmethod
+    def swap_blocks(src_kv_cache: torch.Tensor, dst_kv_cache: torch.Tensor,
+                    src_to_dst: torch.Tensor) -> None:
+        PagedAttention.swap_blocks(src_kv_cache, dst_kv_cache, src_to_dst)
+
+    @staticmethod
+    def copy_blocks(kv_caches: List[torch.Tensor], src_to_dists: torch.Tensor) -> None:
+        PagedAttention.copy_blocks(kv_caches, src_to_dists)
+
+
+# ------------------------------------------------------------------------------------------
+@dataclass
+class PagedEvictMetadata(_MetadataBase):
+    """Per-step attention metadata; field names follow TorchCUDASDPAMetadata
+    (torch_cuda_sdpa.py:91-162)."""
+    num_prefills: int
+    num_prefill_tokens: int
+    num_decode_tokens: int
+    slot_mapping: Optional[torch.Tensor]
+    multi_modal_placeholder_index_maps: Optional[Dict[str, Any]] = None
+    seq_lens_tensor: Optional[torch.Tensor] = None
+    max_decode_seq_len: int = 0
+    block_tables: Optional[torch.Tensor] = None
+    max_prefill_seq_len: int = 0
+    use_cuda_graph: bool = False
+    seq_lens: Optional[List[int]] = None
+    seq_start_loc: Optional[torch.Tensor] = None
+    context_lens_tensor: Optional[torch.Tensor] = None
+    max_query_len: Optional[int] = None
+    max_decode_query_len: Optional[int] = None
+    query_start_loc: Optional[torch.Tensor] = None
+    _cached_prefill_metadata: Optional["PagedEvictMetadata"] = None
+    _cached_decode_metadata: Optional["PagedEvictMetadata"] = None
+    encoder_seq_lens: Optional[List[int]] = None
+    encoder_seq_lens_tensor: Optional[torch.Tensor] = None
+    max_encoder_seq_len: Optional[int] = None
+    num_encoder_tokens: Optional[int] = None
+    cross_slot_mapping: Optional[torch.Tensor] = None
+    cross_block_tables: Optional[torch.Tensor] = None
+    # eviction: physical KV length per sequence (list + device tensor) and the request ->
+    # {seq_id: block table} map of the step
+    seq_kv_lens: Optional[List[int]] = None
+    seq_kv_lens_tensor: Optional[torch.Tensor] = None
+    reqid_mapping_blocktables: Optional[Dict[str, Dict[int, List[int]]]] = None
+
+    def __post_init__(self):
+        self.attn_bias = None
+        # per-step scratch shared by all layers (decision, kept-row index, prefix sums)
+        self._pe_step: Dict[str, Any] = {}
+
+    def asdict_zerocopy(self, skip_fields=None) -> Dict[str, Any]:
+        skip = skip_fields or set()
+        return {f.name: getattr(self, f.name) for f in fields(self) if f.name not in skip}
+
+    @property
+    def prefill_metadata(self) -> Optional["PagedEvictMetadata"]:
+        if self.num_prefills == 0:
+            return None
+        if self._cached_prefill_metadata is not None:
+            return self._cached_prefill_metadata
+        n, nt = self.num_prefills, self.num_prefill_tokens
+
+        def cut(x, k):
+            return None if x is None else x[:k]
+
+        self._cached_prefill_metadata = PagedEvictMetadata(
+            num_prefills=n, num_prefill_tokens=nt, num_decode_tokens=0,
+            slot_mapping=cut(self.slot_mapping, nt),
+            multi_modal_placeholder_index_maps=self.multi_modal_placeholder_index_maps,
+            seq_lens=cut(self.seq_lens, n), seq_lens_tensor=cut(self.seq_lens_tensor, n),
+            max_query_len=self.max_query_len, max_prefill_seq_len=self.max_prefill_seq_len,
+            max_decode_seq_len=0,
+            query_start_loc=cut(self.query_start_loc, n + 1),
+            context_lens_tensor=cut(self.context_lens_tensor, n),
+            block_tables=cut(self.block_tables, n), use_cuda_graph=False,
+            seq_kv_lens=cut(self.seq_kv_lens, n),
+            seq_kv_lens_tensor=cut(self.seq_kv_lens_tensor, n),
+            reqid_mapping_blocktables=self.reqid_mapping_blocktables)
+        return self._cached_prefill_metadata
+
+    @property
+    def decode_metadata(self) -> Optional["PagedEvictMetadata"]:
+        if self.num_decode_tokens == 0:
+            return None
+        if self._cached_decode_metadata is not None:
+            return self._cached_decode_metadata
+        n, nt = self.num_prefills, self.num_prefill_tokens
+
+        def tail(x, k):
+            return None if x is None else x[k:]
+
+        self._cached_decode_metadata = PagedEvictMetadata(
+            num_prefills=0, num_prefill_tokens=0, num_decode_tokens=self.num_decode_tokens,
+            slot_mapping=tail(self.slot_mapping, nt), multi_modal_placeholder_index_maps=None,
+            seq_lens=tail(self.seq_lens, n), seq_lens_tensor=tail(self.seq_lens_tensor, n),
+            max_prefill_seq_len=0, max_decode_seq_len=self.max_decode_seq_len,
+            block_tables=tail(self.block_tables, n), use_cuda_graph=self.use_cuda_graph,
+            seq_kv_lens=tail(self.seq_kv_lens, n),
+            seq_kv_lens_tensor=tail(self.seq_kv_lens_tensor, n),
+            reqid_mapping_blocktables=self.reqid_mapping_blocktables)
+        return self._cached_decode_metadata
+
+    def get_seq_lens(self, attn_type: str = AttentionType.DECODER):
+        """(query lengths, kv lengths); kv lengths are the pruned ones under eviction."""
+        if attn_type not in (AttentionType.DECODER, AttentionType.ENCODER_ONLY):
+            raise AttributeError(f"Invalid attention type {attn_type} for paged eviction")
+        return self.seq_lens, (self.seq_lens if self.seq_kv_lens is None else self.seq_kv_lens)
+
+    def get_seq_len_block_table_args(self, attn_type: str = AttentionType.DECODER):
+        if attn_type not in (AttentionType.DECODER, AttentionType.ENCODER_ONLY):
+            raise AttributeError(f"Invalid attention type {attn_type} for paged eviction")
+        return self.seq_lens_tensor, self.max_decode_seq_len, self.block_tables
+
+
+# ------------------------------------------------------------------------------------------
+def compute_slot_mapping(is_profile_run: bool, is_prompt: bool, slot_mapping: List[int],
+                         seq_id: int, query_len: int, context_len: int, block_size: int,
+                         block_tables: Dict[int, List[int]]) -> None:
+    """Slot ids of a sequence under eviction (torch_cuda_sdpa.py:565-598): a prompt fills every
+    slot of its (already pruned) block table, the last block partially when the prompt length
+    is not a multiple of the block size; a decode step writes slot context_len % block_size of
+    the last block."""
+    if is_profile_run:
+        slot_mapping.extend([PAD_SLOT_ID] * query_len)
+        return
+    table = block_tables[seq_id]
+    if is_prompt:
+        rem = query_len % block_size
+        full = table if rem == 0 else table[:-1]
+        for b in full:
+            slot_mapping.extend(range(b * block_size, (b + 1) * block_size))
+        if rem:
+            slot_mapping.extend(range(table[-1] * block_size, table[-1] * block_size + rem))
+    else:
+        assert query_len == 1, "decode request should have query_len=1 when paged_evict is enabled"
+        slot_mapping.append(table[-1] * block_size + context_len % block_size)
+
+
+class PagedEvictMetadataBuilder(_BuilderBase):
+    """Builds PagedEvictMetadata from the model runner's per-sequence-group data
+    (torch_cuda_sdpa.py:461-697).  Reads from ``input_builder``: ``runner`` (``device``,
+    ``cache_config.paged_evict_config``), ``block_size``, ``sliding_window``,
+    ``chunked_prefill_enabled`` and ``inter_data_list[*].{request_id, is_prompt, block_tables,
+    seq_kv_lens, seq_ids, input_tokens, orig_seq_lens, seq_lens, query_lens, context_lens}``."""
+
+    def __init__(self, input_builder) -> None:
+        self.slot_mapping: List[int] = []
+        self.prefill_seq_lens: List[int] = []
+        self.context_lens: List[int] = []
+        self.block_tables: List[List[int]] = []
+        self.curr_seq_lens: List[int] = []
+        self.num_prefills = 0
+        self.num_prefill_tokens = 0
+        self.num_decode_tokens = 0
+        self.input_builder = input_builder
+        self.runner = input_builder.runner
+        self.sliding_window = input_builder.sliding_window
+        self.block_size = input_builder.block_size
+        self.paged_evict_config = self.runner.cache_config.paged_evict_config
+        self.seq_kv_lens: List[int] = []
+        self.reqid_mapping_blocktables: Dict[str, Dict[int, List[int]]] = {}
+
+    def _add_seq_group(self, inter_data, chunked_prefill_enabled: bool) -> None:
+        if chunked_prefill_enabled and self.paged_evict_config is not None:
+            raise NotImplementedError(
+                "Chunked prefill is not supported when paged eviction is enabled.")
+        if self.sliding_window is not None and self.paged_evict_config is not None:
+            raise AssertionError("Sliding window is not supported when paged_evict is enabled")
+        is_prompt = inter_data.is_prompt
+        block_tables = inter_data.block_tables
+        self.reqid_mapping_blocktables[inter_data.request_id] = block_tables
+        is_profile_run = block_tables is None or all(not t for t in block_tables.values())
+        for seq_id, tokens, seq_len, curr_seq_len, query_len, context_len in zip(
+                inter_data.seq_ids, inter_data.input_tokens, inter_data.orig_seq_lens,
+                inter_data.seq_lens, inter_data.query_lens, inter_data.context_lens):
+            self.context_lens.append(context_len)
+            if is_prompt:
+                self.num_prefills += 1
+                self.num_prefill_tokens += len(tokens)
+                self.prefill_seq_lens.append(seq_len)
+            else:
+                assert query_len == 1, (
+                    f"seq_len: {seq_len}, context_len: {context_len}, query_len: {query_len}")
+                self.num_decode_tokens += query_len
+                self.curr_seq_lens.append(curr_seq_len)
+            table: List[int] = []
+            if not is_prompt and block_tables is not None:
+                table = block_tables[seq_id]
+            self.block_tables.append(table)
+            compute_slot_mapping(is_profile_run, is_prompt, self.slot_mapping, seq_id, query_len,
+                                 context_len, self.block_size, block_tables)
+        if getattr(inter_data, "seq_kv_lens", None) is not None:
+            self.seq_kv_lens.extend(inter_data.seq_kv_lens.values())
+
+    def build(self, seq_lens: List[int], query_lens: List[int], cuda_graph_pad_size: int,
+              batch_size: int) -> PagedEvictMetadata:
+        if cuda_graph_pad_size != -1:
+            # the reference's graph-capture metadata carries no seq_kv_lens either
+            # (vllm/attention/backends/utils.py:316-336); every launch script enforces eager
+            raise NotImplementedError("paged eviction runs in eager mode (--enforce-eager)")
+        for inter_data in self.input_builder.inter_data_list:
+            self._add_seq_group(inter_data,
+                                getattr(self.input_builder, "chunked_prefill_enabled", False))
+        device = self.runner.device
+        max_blocks = max((len(t) for t in self.block_tables), default=0)
+        bt = torch.zeros((len(self.block_tables), max_blocks), dtype=torch.int32)
+        for i, t in enumerate(self.block_tables):
+            if t:
+                bt[i, :len(t)] = torch.tensor(t, dtype=torch.int32)
+
+        def h2d(data, dtype):
+            return torch.tensor(data, dtype=dtype).to(device, non_blocking=True)
+
+        return PagedEvictMetadata(
+            num_prefills=self.num_prefills,
+            slot_mapping=h2d(self.slot_mapping, torch.long),
+            multi_modal_placeholder_index_maps=None,
+            num_prefill_tokens=self.num_prefill_tokens,
+            num_decode_tokens=self.num_decode_tokens,
+            seq_lens=seq_lens,
+            seq_lens_tensor=h2d(seq_lens, torch.int),
+            max_query_len=max(query_lens),
+            max_prefill_seq_len=max(self.prefill_seq_lens, default=0),
+            max_decode_seq_len=max(self.curr_seq_lens, default=0),
+            query_start_loc=h2d(list(accumulate(query_lens, initial=0)), torch.int32),
+            seq_start_loc=h2d(list(accumulate(seq_lens, initial=0)), torch.int32),
+            context_lens_tensor=h2d(self.context_lens, torch.int),
+            block_tables=bt.to(device, non_blocking=True),
+            use_cuda_graph=False,
+            seq_kv_lens=self.seq_kv_lens,
+            seq_kv_lens_tensor=h2d(self.seq_kv_lens, torch.int),
+            reqid_mapping_blocktables=self.reqid_mapping_blocktables)
+
+
+# ------------------------------------------------------------------------------------------
+class DeviceScoreTable:
+    """Block scores of the running sequences, resident on the GPU: f32 [rows, width] plus a
+    count per row; (request, sequence) pairs are mapped to rows on the host.  The device-side
+    counterpart of BlockL2NormManager's per-request lists."""
+
+    def __init__(self, rows: int, width: int, device):
+        self.scores = torch.zeros((rows, width), dtype=torch.float32, device=device)
+        self.counts = torch.zeros(rows, dtype=torch.int32, device=device)
+        self._free = list(range(rows - 1, -1, -1))
+        self._row: Dict[Tuple[str, int], int] = {}
+
+    def row_of(self, key: Tuple[str, int]) -> int:
+        r = self._row.get(key)
+        if r is None:
+            if not self._free:
+                raise RuntimeError("DeviceScoreTable: more live sequences than rows")
+            r = self._free.pop()
+            self._row[key] = r
+            self.counts[r] = 0
+        return r
+
+    def retain_only(self, live: List[Tuple[str, int]]) -> None:
+        live_set = set(live)
+        for key in [k for k in self._row if k not in live_set]:
+            self._free.append(self._row.pop(key))
+
+
+class PagedEvictImpl(_ImplBase):
+    """AttentionImpl of the path.  Constructor and ``forward`` arguments as in
+    abstract.py:222-258 / torch_cuda_sdpa.py:730-836; ``kwargs['cache_config']`` carries the
+    block size and the PagedEvictConfig, ``kwargs['prefix']`` the layer name."""
+
+    def __init__(self, num_heads: int, head_size: int, scale: float,
+                 num_kv_heads: Optional[int] = None, alibi_slopes: Optional[List[float]] = None,
+                 sliding_window: Optional[int] = None, kv_cache_dtype: str = "auto",
+                 blocksparse_params: Optional[Dict[str, Any]] = None,
+                 logits_soft_cap: Optional[float] = None, **kwargs) -> None:
+        if blocksparse_params is not None:
+            raise ValueError("Paged-eviction attention does not support block-sparse attention.")
+        self.num_heads = num_heads
+        self.head_size = head_size
+        self.scale = float(scale)
+        self.num_kv_heads = num_heads if num_kv_heads is None else num_kv_heads
+        self.alibi_slopes = (None if alibi_slopes is None else
+                             torch.tensor(alibi_slopes, dtype=torch.float32))
+        self.sliding_window = sliding_window
+        self.kv_cache_dtype = kv_cache_dtype
+        assert self.num_heads % self.num_kv_heads == 0
+        self.num_queries_per_kv = self.num_heads // self.num_kv_heads
+        if head_size not in PagedAttention.get_supported_head_sizes():
+            raise ValueError(f"Head size {head_size} is not supported by PagedAttention. "
+                             f"Supported head sizes are: {PagedAttention.get_supported_head_sizes()}.")
+        if kv_cache_dtype != "auto":
+            raise NotImplementedError("Paged-eviction attention does not support FP8 KV cache.")
+        if alibi_slopes is not None or sliding_window is not None:
+            # prefill with a bias is outside the eviction path (Llama/OPT use neither)
+            raise NotImplementedError("ALiBi / sliding-window prefill is not implemented")
+
+        self.cache_config = kwargs.get("cache_config", None)
+        self.compat: CompatFlags = kwargs.get("compat", None) or CompatFlags()
+        self.tp_group = kwargs.get("tp_group", None)
+        self.enabled_paged_eviction = False
+        self.kv_cache_pruner: Optional[KVCachePruner] = None
+        self.paged_evict_config: Optional[PagedEvictConfig] = None
+        if self.cache_config is not None and self.cache_config.paged_evict_config is not None:
+            self.enabled_paged_eviction = True
+            self.paged_evict_config = self.cache_config.paged_evict_config
+            self.kv_cache_pruner = KVCachePruner(
+                self.paged_evict_config.cache_prune_type, self.paged_evict_config.evict_method,
+                self.cache_config.block_size, self.paged_evict_config.cache_budget,
+                self.paged_evict_config.initial_blocks,
+                cross_head_compat=self.compat.prompt_prune_cross_head)
+        self.block_l2norm_mgr = BlockL2NormManager()
+        self.prefix: str = kwargs.get("prefix", "")
+        self.layer_idx = _layer_index(self.prefix)
+        random.seed(1234)  # the reference seeds the global RNG in every impl (:796)
+        self.reqids_mapping_rmv_blockIdx: Dict[int, Tuple[str, int]] = {}
+        self._pending_rmv: Optional[torch.Tensor] = None
+        self._score_table: Optional[DeviceScoreTable] = None
+        self.max_num_seqs = int(kwargs.get("max_num_seqs", 256))
+        self.max_blocks_per_seq = int(kwargs.get("max_blocks_per_seq", 4096))
+
+    # ---------------------------------------------------------------------------------- API
+    def get_rmv_block_idx(self) -> Dict[int, Tuple[str, int]]:
+        """{batch index: (request id, block index to free)} decided in the last forward."""
+        if self._pending_rmv is not None:
+            rmv = self._pending_rmv.cpu().tolist()
+            self._pending_rmv = None
+            self.reqids_mapping_rmv_blockIdx = {
+                i: (self.block_l2norm_mgr.get_reqid_and_seqid(i)[0], r)
+                for i, r in enumerate(rmv) if r >= 0}
+        return self.reqids_mapping_rmv_blockIdx
+
+    def forward(self, query: torch.Tensor, key: torch.Tensor, value: torch.Tensor,
+                kv_cache: torch.Tensor, attn_metadata: PagedEvictMetadata, k_scale: float = 1.0,
+                v_scale: float = 1.0, attn_type: str = AttentionType.DECODER,
+                output: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """query [T, Hq*D], key/value [T, Hkv*D], kv_cache [2, nb, bs*Hkv*D] (numel()==0 in the
+        profiling run) -> [T, Hq*D]."""
+        assert k_scale == 1.0 and v_scale == 1.0
+        if attn_type != AttentionType.DECODER:
+            raise NotImplementedError("Paged eviction is only enabled for decoder attention")
+        self.reqids_mapping_rmv_blockIdx = {}
+        self._pending_rmv = None
+        T = query.shape[0]
+        query = query.view(-1, self.num_heads, self.head_size)
+        key = key.view(-1, self.num_kv_heads, self.head_size)
+        value = value.view(-1, self.num_kv_heads, self.head_size)
+        is_profile_run = kv_cache.numel() == 0
+        out = (torch.empty_like(query) if output is None else
+               output.view(-1, self.num_heads, self.head_size))
+        key_cache = value_cache = None
+        if not is_profile_run:
+            key_cache, value_cache = PagedAttention.split_kv_cache(kv_cache, self.num_kv_heads,
+                                                                   self.head_size)
+        if attn_metadata.prefill_metadata is not None and attn_metadata.decode_metadata is not None \
+                and self.enabled_paged_eviction:
+            raise NotImplementedError(
+                "Chunked prefill is not supported when paged eviction is enabled.")
+        if self.enabled_paged_eviction and not is_profile_run:
+            self.block_l2norm_mgr.update_reqs(attn_metadata.reqid_mapping_blocktables)
+
+        if (pm := attn_metadata.prefill_metadata) is not None:
+            self._forward_prefill(out, query, key, value, key_cache, value_cache, attn_metadata, pm,
+                                  is_profile_run)
+        if (dm := attn_metadata.decode_metadata) is not None:
+            self._forward_decode(out, query, key, value, key_cache, value_cache, attn_metadata, dm)
+        return out.view(T, self.num_heads * self.head_size)
+
+    # ------------------------------------------------------------------------------ prefill
+    def _forward_prefill(self, out, query, key, value, key_cache, value_cache, meta, pm,
+                         is_profile_run) -> None:
+        nt = meta.num_prefill_tokens
+        q, k, v = query[:nt], key[:nt], value[:nt]
+        seq_lens = pm.seq_lens
+        step = meta._pe_step
+        cu_q = step.get("cu_q")
+        if cu_q is None:
+            cu_q = pm.query_start_loc if pm.query_start_loc is not None else _cumsum_t(seq_lens, q.device)
+            step["cu_q"] = cu_q
+        max_q = max(seq_lens)
+        cfg = self.paged_evict_config
+        pruner = self.kv_cache_pruner
+        prune = self.enabled_paged_eviction and any(L > cfg.cache_budget for L in seq_lens)
+
+        src_index = kept = None
+        if prune:
+            # streamingLLM index depends on lengths only: built once per step, shared by layers
+            shared = pruner.evict_method in ("streamingLLM", "streamingLLM-1")
+            if shared and "src_index" in step:
+                src_index, kept, cu_kept = step["src_index"], step["kept"], step["cu_kept"]
+            else:
+                kept = [pruner.get_pruned_length(L) for L in seq_lens]
+                cu_kept = step.get("cu_kept")
+                if cu_kept is None:
+                    cu_kept = _cumsum_t(kept, q.device)
+                    step["cu_kept"] = cu_kept
+                    step["kept"] = kept
+                src_index, _ = pruner.keep_index(k, v, seq_lens, cu_q, cu_kept)
+                if shared:
+                    step["src_index"] = src_index
+            pairs = src_index.dim() == 2 and self.compat.prompt_prune_cross_head
+
+        if prune and not cfg.disable_evict_prefill:
+            # evict before attention: attention sees the pruned K/V (top-left causal mask)
+            pk, pv = ops.prompt_prune_gather(k, v, src_index, mode=2 if pairs else None)
+            ops.prefill_causal(q, pk, pv, cu_q, cu_kept, max_q, self.scale, out=out[:nt])
+            if not is_profile_run:
+                PagedAttention.write_to_paged_cache(pk, pv, key_cache, value_cache,
+                                                    meta.slot_mapping[:pk.shape[0]],
+                                                    self.kv_cache_dtype, 1.0, 1.0)
+                self._prompt_block_scores(pv, kept, meta)
+        else:
+            ops.prefill_causal(q, k, v, cu_q, cu_q, max_q, self.scale, out=out[:nt])
+            if not is_profile_run:
+                if prune:
+                    n_kept = src_index.shape[0]
+                    PagedAttention.write_to_paged_cache(
+                        k, v, key_cache, value_cache, meta.slot_mapping[:n_kept],
+                        self.kv_cache_dtype, 1.0, 1.0, src_index=src_index, src_pairs=pairs)
+                    if self._needs_scores():
+                        pk, pv = ops.prompt_prune_gather(k, v, src_index, mode=2 if pairs else None)
+                        self._prompt_block_scores(pv, kept, meta)
+                else:
+                    PagedAttention.write_to_paged_cache(k, v, key_cache, value_cache,
+                                                        meta.slot_mapping[:nt], self.kv_cache_dtype,
+                                                        1.0, 1.0)
+                    if self.enabled_paged_eviction:
+                        self._prompt_block_scores(v, list(seq_lens), meta)
+
+    def _tp_size(self) -> int:
+        return parallel.group_size(self.tp_group) if self.tp_group is not None else 1
+
+    def _needs_scores(self) -> bool:
+        if self._tp_size() > 1 and parallel.group_rank(self.tp_group) != 0:
+            return False
+        return (self.enabled_paged_eviction and not self.compat.random_victim
+                and self.paged_evict_config.evict_method in ("local", "global")
+                and (self.layer_idx <= 0 or self.compat.per_layer_decision))
+
+    def _table(self, device) -> DeviceScoreTable:
+        if self._score_table is None:
+            self._score_table = DeviceScoreTable(2 * self.max_num_seqs, self.max_blocks_per_seq, device)
+        return self._score_table
+
+    def _prompt_block_scores(self, values: torch.Tensor, kept: List[int], meta) -> None:
+        """Scores of every whole block of each (pruned) prompt -> the sequence's score row
+        (torch_cuda_sdpa.py:1278-1288)."""
+        if not self._needs_scores():
+            return
+        bs = self.cache_config.block_size
+        table = self._table(values.device)
+        self._sync_rows(table)
+        off = 0
+        for i, n in enumerate(kept):
+            nb = n // bs
+            row = table.row_of(self.block_l2norm_mgr.get_reqid_and_seqid(i))
+            if nb > 0:
+                self.kv_cache_pruner.get_block_scores_dense(values[off:off + nb * bs], nb,
+                                                            out=table.scores[row, :nb])
+            table.counts[row] = nb
+            off += n
+
+    def _sync_rows(self, table: DeviceScoreTable) -> None:
+        table.retain_only(list(self.block_l2norm_mgr.flat_sequence_map))
+
+    # ------------------------------------------------------------------------------- decode
+    def _forward_decode(self, out, query, key, value, key_cache, value_cache, meta, dm) -> None:
+        n0 = meta.num_prefill_tokens
+        q, k, v = query[n0:], key[n0:], value[n0:]
+        block_tables = dm.block_tables
+        seq_lens_arg = dm.seq_lens_tensor
+        zero_slots = None
+        if self.enabled_paged_eviction:
+            seq_lens_arg = dm.seq_kv_lens_tensor
+            dec = self._decode_decision(meta, dm, value_cache)
+            if dec["tables"] is not None:
+                block_tables = dec["tables"]
+            zero_slots = dec["zero_slots"]
+            self._pending_rmv = dec["rmv"]
+            self.reqids_mapping_rmv_blockIdx = dec["host_rmv"] or {}
+        PagedAttention.write_to_paged_cache(k, v, key_cache, value_cache, dm.slot_mapping,
+                                            self.kv_cache_dtype, 1.0, 1.0, zero_slots=zero_slots)
+        PagedAttention.forward_decode(q, key_cache, value_cache, block_tables, seq_lens_arg,
+                                      dm.max_decode_seq_len, self.kv_cache_dtype, self.num_kv_heads,
+                                      self.scale, None, 1.0, 1.0, output=out[n0:])
+
+    def _decode_decision(self, meta, dm, value_cache) -> Dict[str, Any]:
+        """Eviction decision of this decode step: taken by the first layer that runs and reused
+        by the others (one launch per step), unless per-layer decisions are requested."""
+        step = meta._pe_step
+        if not self.compat.per_layer_decision and "decode" in step:
+            return step["decode"]
+        cfg = self.paged_evict_config
+        bs = self.cache_config.block_size
+        method = cfg.evict_method
+        seq_lens = dm.seq_lens
+        dev = dm.block_tables.device
+        over = [L > cfg.cache_budget for L in seq_lens]
+        trig = [o and L % bs == 0 for o, L in zip(over, seq_lens)]
+        dec: Dict[str, Any] = {"rmv": None, "tables": None, "zero_slots": None, "host_rmv": None}
+        mgr = self.block_l2norm_mgr
+        # width of the compacted table: the longest row once the victims are gone (the
+        # reference always uses M-1 and so can cut a full-length row that evicts nothing)
+        M = dm.block_tables.shape[1]
+        width = M - 1
+        if not self.compat.block_table_slice_in_loop and any(trig):
+            width = max(len(mgr.get_req_block_tables(i)) - (1 if t else 0)
+                        for i, t in enumerate(trig))
+            width = min(max(width, 1), M)
+        if method == "inverse_key_l2":
+            # zero one random middle slot per over-budget sequence (torch_cuda_sdpa.py:1435-1475)
+            slots = []
+            for i, o in enumerate(over):
+                if not o:
+                    continue
+                ids = mgr.get_req_block_tables(i)
+                slots.append(ids[random.randint(1, len(ids) - 2)] * bs + random.randint(0, bs - 1))
+            if slots:
+                dec["zero_slots"] = torch.tensor(slots, dtype=torch.int64).to(dev, non_blocking=True)
+        elif method in ("streamingLLM", "streamingLLM-1"):
+            need_zero = method == "streamingLLM-1" and any(o and not t for o, t in zip(over, trig))
+            if any(trig) or need_zero:
+                rmv, tables, zero = ops.evict_select_compact(
+                    dm.block_tables, dm.seq_lens_tensor, dm.seq_lens_tensor, method,
+                    cfg.cache_budget, bs, compat_q1=self.compat.block_table_slice_in_loop,
+                    compact=any(trig), out_width=width)
+                dec["tables"] = tables if any(trig) else None
+                dec["zero_slots"] = zero
+                dec["host_rmv"] = {i: (mgr.get_reqid_and_seqid(i)[0], 1)
+                                   for i, t in enumerate(trig) if t}
+        elif any(trig):
+            nblk = torch.tensor([len(mgr.get_req_block_tables(i)) for i in range(len(seq_lens))],
+                                dtype=torch.int32).to(dev, non_blocking=True)
+            override = None
+            if self.compat.random_victim:
+                ov = []
+                for i, t in enumerate(trig):
+                    if not t:
+                        ov.append(-1)
+                        continue
+                    n = len(mgr.get_req_block_tables(i))
+                    end = 1 + cfg.topk_blocks if method == "local" else n - 1
+                    ov.append(random.randint(1, end - 1))
+                override = torch.tensor(ov, dtype=torch.int32).to(dev, non_blocking=True)
+                rmv, tables, _ = ops.evict_select_compact(
+                    dm.block_tables, dm.seq_lens_tensor, nblk, method, cfg.cache_budget, bs,
+                    cfg.topk_blocks, victim_override=override,
+                    compat_q1=self.compat.block_table_slice_in_loop, out_width=width)
+                dec["host_rmv"] = {i: (mgr.get_reqid_and_seqid(i)[0], r)
+                                   for i, r in enumerate(ov) if r >= 0}
+            elif self._tp_size() > 1 and parallel.group_rank(self.tp_group) != 0:
+                # data-dependent victims are decided by the first rank of the TP group and
+                # broadcast; this rank only applies them
+                rmv = torch.empty(len(seq_lens), dtype=torch.int32, device=dev)
+                parallel.broadcast_victims(rmv, self.tp_group, 0)
+                _, tables, _ = ops.evict_select_compact(
+                    dm.block_tables, dm.seq_lens_tensor, nblk, method, cfg.cache_budget, bs,
+                    cfg.topk_blocks, victim_override=rmv,
+                    compat_q1=self.compat.block_table_slice_in_loop, out_width=width)
+                dec["rmv"] = rmv
+            else:
+                table = self._table(dev)
+                self._sync_rows(table)
+                rows = torch.tensor([table.row_of(mgr.get_reqid_and_seqid(i))
+                                     for i in range(len(seq_lens))], dtype=torch.int32).to(dev)
+                rmv, tables, _ = ops.evict_select_compact(
+                    dm.block_tables, dm.seq_lens_tensor, nblk, method, cfg.cache_budget, bs,
+                    cfg.topk_blocks, drop_victim_score=not self.compat.keep_victim_score,
+                    compat_q1=self.compat.block_table_slice_in_loop,
+                    score_layout=(ops.SCORE_CACHE_FLAT if self.compat.score_flat_cache_view
+                                  else ops.SCORE_CACHE),
+                    score_table=table.scores, score_counts=table.counts, score_rows=rows,
+                    value_cache=value_cache, out_width=width)
+                if self._tp_size() > 1:
+                    parallel.broadcast_victims(rmv, self.tp_group, 0)
+                dec["rmv"] = rmv
+            dec["tables"] = tables
+        if not self.compat.per_layer_decision:
+            step["decode"] = dec
+        return dec
+
+
+def _layer_index(prefix: str) -> int:
+    """First integer component of a dotted layer name ('model.layers.3.self_attn.attn' -> 3)."""
+    for part in prefix.split("."):
+        if part.isdigit():
+            return int(part)
+    return -1
+
+
+def _cumsum_t(lens, device) -> torch.Tensor:
+    return torch.tensor(list(accumulate(lens, initial=0)), dtype=torch.int32, device=device)
+
+
+def get_attn_backend_for_eviction(cache_config) -> Optional[Type[PagedEvictBackend]]:
+    """Selector hook: the backend class to use when ``--enable-paged-eviction`` is set
+    (replaces the TORCH_SDPA branch of vllm/attention/selector.py:138-146, which ROCm's
+    platform override vllm/platforms/rocm.py:47-57 never reaches)."""
+    if cache_config is not None and getattr(cache_config, "paged_evict_config", None) is not None:
+        return PagedEvictBackend
+    return None

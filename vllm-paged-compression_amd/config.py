@@ -1,0 +1,100 @@
+"""Eviction flags: the validated config object of the path.
+
+``PagedEvictConfig`` has the constructor arguments, attributes and validation of the
+reference's vllm/config.py:933-991 (flags: vllm/engine/arg_utils.py:971-1036), so an
+instance built by the fork's ``EngineArgs`` can be used as is, and vice versa.  Extra,
+build-specific switches live in ``CompatFlags`` (all default to the intended semantics).
+"""
+from __future__ import annotations
+
+import logging
+from dataclasses import dataclass
+from typing import Optional
+
+logger = logging.getLogger(__name__)
+
+EVICT_METHODS = ("streamingLLM", "streamingLLM-1", "inverse_key_l2", "local", "global")
+
+
+class PagedEvictConfig:
+    """--enable-paged-eviction flags.
+
+    disable_evict_prefill: attend the full prompt, prune when writing the cache
+    cache_prune_type:      "budget" ("percentage" is parsed but rejected, as at the reference's HEAD)
+    evict_method:          one of EVICT_METHODS
+    cache_budget:          tokens kept per sequence (clamped up to 128)
+    topk_blocks:           candidate window of "local" (> 1); forced to -1 for "global"
+    """
+
+    def __init__(self, disable_evict_prefill: bool, cache_prune_type: str, evict_method: str,
+                 cache_budget: int, topk_blocks: int) -> None:
+        self.disable_evict_prefill = disable_evict_prefill
+        self.cache_prune_type = cache_prune_type
+        self.evict_method = evict_method
+        self.cache_budget = cache_budget
+        self.topk_blocks = topk_blocks
+        self.initial_blocks = 1  # blocks at the head of the sequence that are never evicted
+        self._verify_args()
+
+    def _verify_args(self) -> None:
+        if self.cache_prune_type not in ("percentage", "budget"):
+            raise ValueError("Cache prune type must be either 'percentage' or 'budget'. Got "
+                             f"{self.cache_prune_type}.")
+        assert self.cache_prune_type == "budget", \
+            "Cache prune type must be 'budget' for paged compression now."
+        if self.evict_method not in EVICT_METHODS:
+            raise ValueError(f"Unknown evict method {self.evict_method!r}; expected one of "
+                             f"{EVICT_METHODS}.")
+        if self.cache_budget < 0:
+            raise ValueError(f"Cache budget must be positive. Got {self.cache_budget}.")
+        if self.cache_budget < 128:
+            logger.warning("Cache budget is set to less than 128 tokens. "
+                           "Setting cache budget to 128 tokens.")
+            self.cache_budget = 128
+        if self.evict_method == "local" and self.topk_blocks <= 1:
+            raise ValueError("Topk blocks must be > 1 when using 'local' evict method. "
+                             f"Got {self.topk_blocks}.")
+        if self.evict_method == "global":
+            self.topk_blocks = -1
+
+    def __repr__(self) -> str:
+        return (f"PagedEvictConfig(disable_evict_prefill={self.disable_evict_prefill}, "
+                f"cache_prune_type={self.cache_prune_type!r}, evict_method={self.evict_method!r}, "
+                f"cache_budget={self.cache_budget}, topk_blocks={self.topk_blocks})")
+
+
+def budget_from_percentage(evict_fraction: float, input_len: int, block_size: int) -> int:
+    """Budget that keeps (1 - evict_fraction) of an input_len-token prompt, rounded down to a
+    whole number of blocks (the benchmark configs are worded as "25 % / 50 % eviction")."""
+    if not 0.0 <= evict_fraction < 1.0:
+        raise ValueError("evict_fraction must be in [0, 1)")
+    return max(int((1.0 - evict_fraction) * input_len) // block_size * block_size, 3 * block_size)
+
+
+@dataclass
+class CompatFlags:
+    """Switches that reproduce behaviours of the reference's HEAD that differ from the
+    intended algorithm.  Defaults = intended semantics."""
+    # in-loop slice of _create_updated_block_tables (torch_cuda_sdpa.py:1583)
+    block_table_slice_in_loop: bool = False
+    # middle[mask].view(-1, H, D) re-packing across heads (kvcache_prunner.py:251-252)
+    prompt_prune_cross_head: bool = False
+    # decode-time block score read through a flat re-view of the cache block (:1521-1524)
+    score_flat_cache_view: bool = False
+    # never delete the victim's score (:1546 commented out), so the list outgrows the table
+    keep_victim_score: bool = False
+    # random victim instead of arg-min (enable_random_evict = True, :802)
+    random_victim: bool = False
+    # every layer takes its own decision; only layer 0's is committed (model_runner.py:1797-1802)
+    per_layer_decision: bool = False
+
+    @classmethod
+    def reference_head(cls) -> "CompatFlags":
+        return cls(True, True, True, True, True, True)
+
+
+@dataclass
+class CacheConfigView:
+    """The two attributes of vLLM's CacheConfig this path reads."""
+    block_size: int
+    paged_evict_config: Optional[PagedEvictConfig] = None

@@ -76,8 +76,8 @@ __global__ __launch_bounds__(64) void evict_select_compact_kernel(
     int32_t* __restrict__ rmv_idx_out, int32_t* __restrict__ out_tables,
     int64_t* __restrict__ zero_slots_out, const int32_t* __restrict__ block_tables,
     const int32_t* __restrict__ seq_lens, const int32_t* __restrict__ num_blocks,
-    const int32_t* __restrict__ victim_override, int batch, int max_blocks, int method,
-    int cache_budget, int block_size, int topk_blocks, int drop_victim_score, int compat_q1,
+    const int32_t* __restrict__ victim_override, int batch, int max_blocks, int out_width,
+    int method, int cache_budget, int block_size, int topk_blocks, int drop_victim_score, int compat_q1,
     int score_layout, float* __restrict__ score_table, int32_t* __restrict__ score_counts,
     const int32_t* __restrict__ score_rows, int score_table_width,
     const T* __restrict__ value_cache, int64_t kv_block_stride, int num_kv_heads, int head_size) {
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(64) void evict_select_compact_kernel(
   const int lane = threadIdx.x;
   const int b_begin = compat_q1 ? 0 : blockIdx.x;
   const int b_end = compat_q1 ? batch : blockIdx.x + 1;
-  const int w = max_blocks - 1;
+  const int w = out_width;
 
   for (int b = b_begin; b < b_end; ++b) {
     const int seq_len = seq_lens[b];
@@ -175,7 +175,10 @@ __global__ __launch_bounds__(64) void evict_select_compact_kernel(
     if (out_tables != nullptr && w > 0) {
       int32_t* o = out_tables + (int64_t)b * w;
       if (!compat_q1 || b == 0) {
-        for (int j = lane; j < w; j += 64) o[j] = (rmv >= 0 && j >= rmv) ? row[j + 1] : row[j];
+        for (int j = lane; j < w; j += 64) {
+          const int src = (rmv >= 0 && j >= rmv) ? j + 1 : j;
+          o[j] = src < max_blocks ? row[src] : 0;
+        }
       } else {
         // rows after the first see a table already cut to width w by the reference's slice
         // inside its loop: removing a column leaves w-1 new entries and the old last one stays
@@ -221,7 +224,7 @@ int pe_block_score_value_l2(float* scores_out, const void* values, const int32_t
 int pe_evict_select_compact(int32_t* rmv_idx_out, int32_t* out_tables, int64_t* zero_slots_out,
                             const int32_t* block_tables, const int32_t* seq_lens,
                             const int32_t* num_blocks, const int32_t* victim_override, int batch,
-                            int max_blocks, int method, int cache_budget, int block_size,
+                            int max_blocks, int out_width, int method, int cache_budget, int block_size,
                             int topk_blocks, int drop_victim_score, int compat_q1,
                             int score_layout, float* score_table, int32_t* score_counts,
                             const int32_t* score_rows, int score_table_width,
@@ -237,6 +240,10 @@ int pe_evict_select_compact(int32_t* rmv_idx_out, int32_t* out_tables, int64_t* 
   PE_REQUIRE(block_size > 0 && max_blocks >= 2 && cache_budget >= 3 * block_size,
              PE_ERR_INVALID_ARG,
              "need block_size > 0, a table at least 2 blocks wide and a budget of >= 3 blocks");
+  PE_REQUIRE(out_tables == nullptr || (out_width >= 1 && out_width <= max_blocks),
+             PE_ERR_INVALID_ARG, "out_width %d must be in [1, max_blocks=%d]", out_width, max_blocks);
+  PE_REQUIRE(!compat_q1 || out_tables == nullptr || out_width == max_blocks - 1, PE_ERR_INVALID_ARG,
+             "the reference-compatible compaction has width max_blocks-1");
   PE_REQUIRE(method != PE_EVICT_STREAMING_1 || zero_slots_out, PE_ERR_INVALID_ARG,
              "streamingLLM-1 needs zero_slots_out");
   size_t lds = 0;
@@ -260,7 +267,7 @@ int pe_evict_select_compact(int32_t* rmv_idx_out, int32_t* out_tables, int64_t* 
                   hipLaunchKernelGGL(evict_select_compact_kernel<T>, dim3(grid), dim3(64), lds,
                                      static_cast<hipStream_t>(stream), rmv_idx_out, out_tables,
                                      zero_slots_out, block_tables, seq_lens, num_blocks,
-                                     victim_override, batch, max_blocks, method, cache_budget,
+                                     victim_override, batch, max_blocks, out_width, method, cache_budget,
                                      block_size, topk_blocks, drop_victim_score, compat_q1,
                                      score_layout, score_table, score_counts, score_rows,
                                      score_table_width, (const T*)value_cache, kv_block_stride,

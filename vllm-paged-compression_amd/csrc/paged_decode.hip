@@ -67,7 +67,8 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void paged_decode_mfma_kernel(
   const int g = lane >> 4;   // lane group: tokens 4g..4g+3 of a block
   const int hc = lane & 15;  // query head within the group (column of S^T / O^T)
 
-  const int seq_len = seq_lens[seq];
+  // a length beyond what the table row can address is clamped (never read past the row)
+  const int seq_len = min(seq_lens[seq], max_num_blocks_per_seq * BS);
   const int n_blocks = (seq_len + BS - 1) / BS;
   const int n_pairs = (n_blocks + 1) / 2;
   const int pairs_per_split = (n_pairs + num_splits - 1) / num_splits;
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(256) void paged_decode_generic_kernel(
     const T* __restrict__ value_cache, const int32_t* __restrict__ block_tables,
     const int32_t* __restrict__ seq_lens, const float* __restrict__ alibi_slopes, int num_heads,
     int num_kv_heads, int head_size, int block_size, int max_num_blocks_per_seq, int64_t q_stride,
-    int64_t kv_block_stride, int64_t kv_head_stride, float scale) {
+    int64_t kv_block_stride, int64_t kv_head_stride, float scale, int max_len) {
   constexpr int X = 16 / sizeof(T);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* q_s = reinterpret_cast<float*>(smem);       // [head_size]
@@ -291,7 +292,8 @@ __global__ __launch_bounds__(256) void paged_decode_generic_kernel(
   float* logits = red + 8;                            // [seq_len]
   const int head = blockIdx.x, seq = blockIdx.y;
   const int kvh = head / (num_heads / num_kv_heads);
-  const int seq_len = seq_lens[seq];
+  // clamped to what the table row addresses and to the LDS logits buffer
+  const int seq_len = min(seq_lens[seq], min(max_num_blocks_per_seq * block_size, max_len));
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int32_t* table = block_tables + (int64_t)seq * max_num_blocks_per_seq;
   const float slope = alibi_slopes ? alibi_slopes[head] : 0.f;
@@ -412,9 +414,9 @@ int pe_paged_decode(void* out, const void* query, const void* key_cache, const v
              num_heads, num_kv_heads);
   PE_REQUIRE(head_size > 0 && block_size > 0 && max_num_blocks_per_seq > 0 && max_seq_len >= 0,
              PE_ERR_INVALID_ARG, "paged_decode: bad sizes");
-  PE_REQUIRE((int64_t)max_num_blocks_per_seq * block_size >= max_seq_len, PE_ERR_INVALID_ARG,
-             "block table width %d x block %d cannot hold max_seq_len %d", max_num_blocks_per_seq,
-             block_size, max_seq_len);
+  // max_seq_len is an upper bound used for sizing only: under eviction the reference passes the
+  // logical (unpruned) maximum here (torch_cuda_sdpa.py:446-447), which may exceed what the
+  // compacted table addresses
   const int x = 16 / elem_size(dtype);
   PE_REQUIRE(head_size % x == 0, PE_ERR_UNSUPPORTED, "head_size %d not a multiple of %d", head_size, x);
   PE_REQUIRE(num_seqs <= 65535 && num_kv_heads <= 65535, PE_ERR_UNSUPPORTED, "grid too large");
@@ -456,7 +458,9 @@ int pe_paged_decode(void* out, const void* query, const void* key_cache, const v
   }
 
   // generic path
-  const size_t lds = (size_t)(((head_size + 3) & ~3) + 8 + max_seq_len) * 4;
+  int gen_len = max_seq_len;
+  if ((int64_t)max_num_blocks_per_seq * block_size < gen_len) gen_len = max_num_blocks_per_seq * block_size;
+  const size_t lds = (size_t)(((head_size + 3) & ~3) + 8 + gen_len) * 4;
   PE_REQUIRE(lds <= 160 * 1024, PE_ERR_UNSUPPORTED,
              "generic decode path holds the logits in LDS: max_seq_len %d too long for "
              "head_size %d / block_size %d / dtype %d",
@@ -472,7 +476,7 @@ int pe_paged_decode(void* out, const void* query, const void* key_cache, const v
                        (const T*)query, (const T*)key_cache, (const T*)value_cache,             \
                        block_tables, seq_lens, alibi_slopes, num_heads, num_kv_heads, head_size, \
                        block_size, max_num_blocks_per_seq, q_stride, kv_block_stride,           \
-                       kv_head_stride, scale);                                                  \
+                       kv_head_stride, scale, gen_len);                                         \
   } while (0)
   PE_DISPATCH_ALL(dtype, T, PE_LAUNCH_GEN(T));
 #undef PE_LAUNCH_GEN

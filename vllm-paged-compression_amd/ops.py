@@ -339,9 +339,10 @@ def evict_select_compact(block_tables: torch.Tensor, seq_lens: torch.Tensor,
                          score_counts: Optional[torch.Tensor] = None,
                          score_rows: Optional[torch.Tensor] = None,
                          value_cache: Optional[torch.Tensor] = None,
-                         compact: bool = True):
-    """One launch per decode step: returns (rmv_idx int32[B], compacted tables int32[B, M-1] or
-    None, zero_slots int64[B] or None)."""
+                         compact: bool = True, out_width: Optional[int] = None):
+    """One launch per decode step: returns (rmv_idx int32[B], compacted tables int32[B, out_width]
+    or None, zero_slots int64[B] or None).  out_width defaults to the reference's M-1; pass the
+    longest surviving row when a row that evicts nothing may be M blocks long."""
     dev = _need_gpu(block_tables, seq_lens, num_blocks, victim_override, score_table,
                     score_counts, score_rows, value_cache)
     B, M = block_tables.shape
@@ -350,7 +351,9 @@ def evict_select_compact(block_tables: torch.Tensor, seq_lens: torch.Tensor,
             raise RuntimeError("evict_select_compact: int32 contiguous tensors expected")
     m = EVICT_METHODS[method]
     rmv = torch.empty(B, dtype=torch.int32, device=dev)
-    out_tables = torch.empty((B, max(M - 1, 0)), dtype=torch.int32, device=dev) if compact else None
+    if out_width is None:
+        out_width = max(M - 1, 1)
+    out_tables = torch.empty((B, out_width), dtype=torch.int32, device=dev) if compact else None
     zero = torch.empty(B, dtype=torch.int64, device=dev) if m == 1 else None
     Hkv = D = 0
     kv_stride = 0
@@ -372,7 +375,7 @@ def evict_select_compact(block_tables: torch.Tensor, seq_lens: torch.Tensor,
     lib = _lib.load()
     _lib.check(lib.pe_evict_select_compact(
         _p(rmv), _p(out_tables), _p(zero), _p(block_tables), _p(seq_lens), _p(num_blocks),
-        _p(victim_override), B, M, m, cache_budget, block_size, topk_blocks,
+        _p(victim_override), B, M, out_width, m, cache_budget, block_size, topk_blocks,
         1 if drop_victim_score else 0, 1 if compat_q1 else 0, score_layout, _p(score_table),
         _p(score_counts), _p(score_rows), width, _p(value_cache), kv_stride, Hkv, D, dt,
         _stream(dev)), "evict_select_compact")

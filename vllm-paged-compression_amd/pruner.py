@@ -1,0 +1,135 @@
+"""KVCachePruner: prompt pruning and block scoring, with the constructor and method names of
+the reference's vllm/attention/kvcache_prunner.py:6-326, over the HIP operators.
+
+Length arithmetic (``get_pruned_length``) runs on the host; everything that touches K/V
+runs on the GPU: the kept rows are described by an int32 index built on the device
+(streamingLLM: a closed-form map; local/global/inverse_key_l2: per-head radix select of the
+lowest scores) and applied either as a dense gather (``prune_prompt``) or fused into the
+KV-cache write (``ops.reshape_and_cache(..., src_index=...)``).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import ops
+
+_STREAMING = ("streamingLLM", "streamingLLM-1")
+_TOKEN_LEVEL = ("local", "global", "inverse_key_l2")
+
+
+class KVCachePruner:
+
+    def __init__(self, cache_prune_type: str, evict_method: str, block_size: int,
+                 cache_budget: int, initial_blocks: int, *, cross_head_compat: bool = False):
+        assert cache_prune_type == "budget"
+        assert cache_budget >= 3 * block_size, \
+            "Cache budget must be at least 3 times the original block size"
+        if evict_method not in _STREAMING + _TOKEN_LEVEL:
+            raise ValueError(f"Unknown eviction method: {evict_method}")
+        self.cache_prune_type = cache_prune_type
+        self.evict_method = evict_method
+        self.orig_block_size = block_size
+        self.cache_budget = cache_budget
+        self.sub_evict_method = "value_l2"   # score used by "global" and "local"
+        self.initial_blocks = initial_blocks
+        self.cross_head_compat = cross_head_compat
+
+    # ------------------------------------------------------------------ host arithmetic
+    def get_pruned_length(self, seq_len: int) -> int:
+        """Tokens kept of a seq_len-token prompt: first block + budgeted middle + last block
+        (+ remainder)."""
+        if seq_len <= self.cache_budget:
+            return seq_len
+        bs = self.orig_block_size
+        end_middle = seq_len - bs - seq_len % bs
+        return bs + max(self.cache_budget - 2 * bs, 0) + (seq_len - end_middle)
+
+    # ------------------------------------------------------------------ device index
+    def keep_index(self, key: torch.Tensor, value: torch.Tensor, seq_lens: Sequence[int],
+                   cu_q: Optional[torch.Tensor] = None,
+                   cu_kept: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, List[int]]:
+        """Kept-row index for a batch of prompts laid out back to back in key/value
+        ([sum(seq_lens), H, D]).  Returns (int32 index, kept length per prompt); the index is
+        [n_kept] for the streamingLLM methods and [n_kept, H] (per head) otherwise."""
+        kept = [self.get_pruned_length(L) for L in seq_lens]
+        dev = key.device
+        if cu_q is None:
+            cu_q = _cumsum(seq_lens, dev)
+        if cu_kept is None:
+            cu_kept = _cumsum(kept, dev)
+        total = sum(kept)
+        if self.evict_method in _STREAMING:
+            idx = ops.prompt_keep_index_streaming(cu_q, cu_kept, total, self.cache_budget,
+                                                  self.orig_block_size)
+        else:
+            idx = ops.prompt_token_select(key, value, cu_q, cu_kept, total, self.cache_budget,
+                                          self.orig_block_size, self.evict_method,
+                                          compat_q2=self.cross_head_compat)
+        return idx, kept
+
+    def _gather(self, key, value, idx):
+        mode = None
+        if idx.dim() == 2 and self.cross_head_compat:
+            mode = 2
+        return ops.prompt_prune_gather(key, value, idx, mode=mode)
+
+    # ------------------------------------------------------------------ reference-shaped API
+    def prune_prompt(self, key_tensor: torch.Tensor, value_tensor: torch.Tensor):
+        """Prune one request's prompt K/V ([L, H, D]) -> ([n_kept, H, D], same)."""
+        L = key_tensor.shape[0]
+        if L <= self.cache_budget:
+            return key_tensor, value_tensor
+        idx, _ = self.keep_index(key_tensor, value_tensor, [L])
+        return self._gather(key_tensor, value_tensor, idx)
+
+    def prune_prompt_inplace(self, key_tensor, value_tensor, output_key_tensor,
+                             output_value_tensor) -> None:
+        """Same, writing into caller-provided [n_kept, H, D] tensors."""
+        k, v = self.prune_prompt(key_tensor, value_tensor)
+        output_key_tensor.copy_(k)
+        output_value_tensor.copy_(v)
+
+    def prune_prompts_batch(self, key: torch.Tensor, value: torch.Tensor,
+                            seq_lens: Sequence[int]):
+        """All prompts of a prefill batch in one go (the reference loops over requests on 8
+        side streams, torch_cuda_sdpa.py:1222-1296).  Returns (keys, values, kept lengths)."""
+        if all(L <= self.cache_budget for L in seq_lens):
+            return key, value, list(seq_lens)
+        idx, kept = self.keep_index(key, value, seq_lens)
+        k, v = self._gather(key, value, idx)
+        return k, v, kept
+
+    def get_token_score(self, keys: torch.Tensor, values: torch.Tensor, evict_method: str):
+        """[T, H] scores: ||V||_2 for global/local, 1/(||K||_2+1e-8) for inverse_key_l2."""
+        if evict_method in ("global", "local"):
+            return torch.norm(values, p=2, dim=-1)
+        if evict_method == "inverse_key_l2":
+            return torch.div(1, torch.norm(keys, p=2, dim=-1) + 1e-8)
+        raise ValueError(f"Unknown eviction method: {evict_method}")
+
+    def get_block_score(self, block_keys: torch.Tensor, block_values: torch.Tensor,
+                        evict_method: str) -> torch.Tensor:
+        """value_l2 score of one [block_size, H, D] block (0-d tensor of the input dtype)."""
+        assert evict_method in ("global", "local"), \
+            "Only global and local eviction methods are supported for block score calculation"
+        bs, H, D = block_values.shape
+        s = ops.block_score_value_l2(block_values.contiguous(), None, 1, ops.SCORE_TOKEN_MAJOR,
+                                     H, D, bs)
+        return s[0].to(block_values.dtype)
+
+    def get_block_scores_dense(self, values: torch.Tensor, n_blocks: int,
+                               out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Scores of the first n_blocks whole blocks of a dense [T, H, D] value tensor
+        (the prompt-time loop of torch_cuda_sdpa.py:1278-1288 as one launch); f32 [n_blocks]."""
+        T, H, D = values.shape
+        return ops.block_score_value_l2(values, None, n_blocks, ops.SCORE_TOKEN_MAJOR, H, D,
+                                        self.orig_block_size, out=out)
+
+
+def _cumsum(lens: Sequence[int], device) -> torch.Tensor:
+    out = [0]
+    for n in lens:
+        out.append(out[-1] + int(n))
+    return torch.tensor(out, dtype=torch.int32, device=device)
