@@ -1,0 +1,355 @@
+#!/usr/bin/env python3
+"""Benchmark of the paged-KV-eviction attention hot path on MI355X.
+
+One "step" = one full generation of a batch of synthetic requests through the hot path
+of every layer: prefill attention + prompt prune + KV write for the prompts, then
+output_len decode steps of (eviction decision + block-table compaction + KV write + paged
+decode attention), driven by the same host code a serving engine would run (scheduler,
+metadata builder, backend impl).  The model's GEMMs/MLP are outside the path and not run.
+
+Default workload (BASELINE.json configs[1]): Llama-3-8B attention geometry (32 query heads,
+8 KV heads, head 128, 32 layers, bf16), block size 16, input 1024 -> output 100, 64 requests
+(the reference's sweep scripts use 64), 25 % eviction => cache budget 768, streamingLLM
+prompt prune, value_l2 ("global") block eviction at decode.
+
+  python bench.py --gpus 1 --steps 3 --warmup 1
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N   (tensor parallel)
+
+Prints one JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--num-prompts", type=int, default=64)
+    ap.add_argument("--input-len", type=int, default=1024)
+    ap.add_argument("--output-len", type=int, default=100)
+    ap.add_argument("--evict", type=float, default=0.25, help="fraction of the prompt evicted (0 = off)")
+    ap.add_argument("--cache-budget", type=int, default=0, help="overrides --evict when > 0")
+    ap.add_argument("--prompt-evict-method", default="streamingLLM")
+    ap.add_argument("--decode-evict-method", default="value_l2",
+                    help="streamingLLM | streamingLLM-1 | value_l2 (= global) | local | global")
+    ap.add_argument("--evict-freq", type=int, default=0, help="accepted for README compatibility; unused")
+    ap.add_argument("--evict-prefill", action="store_true",
+                    help="prune before prefill attention (default: attend the full prompt, as the "
+                         "reference's scripts do with --disable-evict-prefill)")
+    ap.add_argument("--layers", type=int, default=32)
+    ap.add_argument("--num-heads", type=int, default=32)
+    ap.add_argument("--num-kv-heads", type=int, default=8)
+    ap.add_argument("--head-size", type=int, default=128)
+    ap.add_argument("--block-size", type=int, default=16)
+    ap.add_argument("--prefill-batch", type=int, default=8, help="prompts per prefill step")
+    ap.add_argument("--mode", choices=["tp", "dp"], default="tp",
+                    help="N>1: tp = heads sharded over ranks (strong scaling); dp = replicas (weak)")
+    ap.add_argument("--no-oproj-allreduce", action="store_true",
+                    help="tp: skip the all-reduce of the [tokens, hidden] o_proj output after each layer")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--time-layer", type=int, default=1, help="layer whose decode launches are event-timed")
+    return ap.parse_args()
+
+
+class Workload:
+    """Drives one generation through the backend with a private scheduler and KV cache."""
+
+    def __init__(self, a, dev, tp_size, tp_rank, tp_group):
+        from vllm_paged_compression_amd.backend import PagedEvictBackend
+        from vllm_paged_compression_amd.config import (CacheConfigView, PagedEvictConfig,
+                                                       budget_from_percentage)
+        from vllm_paged_compression_amd.parallel import shard_heads
+        self.a, self.dev = a, dev
+        self.tp_size, self.tp_group = tp_size, tp_group
+        sh = shard_heads(a.num_heads, a.num_kv_heads, tp_size, tp_rank)
+        self.Hq, self.Hkv, self.D, self.bs = sh.num_heads, sh.num_kv_heads, a.head_size, a.block_size
+        self.hidden = a.num_heads * a.head_size
+        self.cfg = None
+        self.budget = 0
+        method = {"value_l2": "global"}.get(a.decode_evict_method, a.decode_evict_method)
+        if a.evict > 0 or a.cache_budget > 0:
+            self.budget = a.cache_budget or budget_from_percentage(a.evict, a.input_len, a.block_size)
+            self.cfg = PagedEvictConfig(not a.evict_prefill, "budget", method, self.budget, 3)
+        self.ccfg = CacheConfigView(a.block_size, self.cfg)
+        self.backend = PagedEvictBackend
+        B = a.num_prompts
+        kept = a.input_len if self.cfg is None else min(a.input_len, self.budget + a.input_len % a.block_size)
+        max_kv = (a.input_len + a.output_len) if self.cfg is None else kept + a.block_size + 1
+        self.blocks_per_seq = -(-max_kv // a.block_size) + 1
+        self.blocks_per_seq_full = -(-(a.input_len + a.output_len) // a.block_size)
+        self.num_blocks = B * self.blocks_per_seq + 8
+        shape = PagedEvictBackend.get_kv_cache_shape(self.num_blocks, self.bs, self.Hkv, self.D)
+        self.kv = [torch.zeros(shape, dtype=torch.bfloat16, device=dev) for _ in range(a.layers)]
+        self.impls = [PagedEvictBackend.get_impl_cls()(
+            self.Hq, self.D, self.D ** -0.5, self.Hkv, None, None, "auto", None, None,
+            cache_config=self.ccfg, prefix=f"model.layers.{i}.self_attn.attn",
+            prompt_evict_method=a.prompt_evict_method if self.cfg is not None else None,
+            tp_group=tp_group, max_num_seqs=B, max_blocks_per_seq=4 * self.blocks_per_seq_full)
+            for i in range(a.layers)]
+        g = torch.Generator(device=dev).manual_seed(1234 + tp_rank)
+        sc = self.D ** -0.5
+
+        def rnd(T, H):
+            return torch.empty(T, H * self.D, dtype=torch.bfloat16, device=dev).uniform_(-sc, sc, generator=g)
+
+        Tp = a.prefill_batch * a.input_len
+        self.qp, self.kp, self.vp = rnd(Tp, self.Hq), rnd(Tp, self.Hkv), rnd(Tp, self.Hkv)
+        self.qd, self.kd, self.vd = rnd(B, self.Hq), rnd(B, self.Hkv), rnd(B, self.Hkv)
+        self.o_partial_p = torch.zeros(Tp, self.hidden, dtype=torch.bfloat16, device=dev)
+        self.o_partial_d = torch.zeros(B, self.hidden, dtype=torch.bfloat16, device=dev)
+        self.allreduce = tp_size > 1 and not a.no_oproj_allreduce
+        # decode-kernel timing (HIP events on the launch stream) of one layer
+        self.timed = []          # (start_event, end_event, algorithmic_bytes)
+        self.timing_on = False
+        self.kv_blocks_peak = 0
+
+    # ---- metadata -------------------------------------------------------------------------
+    def _build(self, inter, seq_lens, q_lens):
+        runner = SimpleNamespace(device=self.dev, cache_config=self.ccfg, pin_memory=False)
+        ib = SimpleNamespace(runner=runner, sliding_window=None, block_size=self.bs,
+                             chunked_prefill_enabled=False, inter_data_list=inter)
+        return self.backend.make_metadata_builder(ib).build(seq_lens, q_lens, -1, len(seq_lens))
+
+    def _layers(self, q, k, v, meta, o_partial, decode_bytes=None):
+        from vllm_paged_compression_amd import parallel
+        for li, impl in enumerate(self.impls):
+            if decode_bytes is not None and self.timing_on and li == self.a.time_layer % len(self.impls):
+                self._timed_forward(impl, q, k, v, self.kv[li], meta, decode_bytes)
+            else:
+                impl.forward(q, k, v, self.kv[li], meta)
+            if self.allreduce:
+                parallel.all_reduce_sum(o_partial, self.tp_group)
+
+    def _timed_forward(self, impl, q, k, v, kv, meta, nbytes):
+        """Event-brackets only the decode-attention launch inside forward()."""
+        from vllm_paged_compression_amd import ops
+        sink = []
+        ops.DecodeLayerLauncher.event_sink = sink
+        try:
+            impl.forward(q, k, v, kv, meta)
+        finally:
+            ops.DecodeLayerLauncher.event_sink = None
+        for s, e in sink:
+            self.timed.append((s, e, nbytes))
+
+    # ---- one generation ---------------------------------------------------------------------
+    def generate(self):
+        from vllm_paged_compression_amd.block_table import EvictBlockSpaceManager, EvictionScheduler
+        a, bs = self.a, self.bs
+        B, L0 = a.num_prompts, a.input_len
+        sched = EvictionScheduler(EvictBlockSpaceManager(bs, self.num_blocks, self.cfg, watermark=0.0))
+        bm = sched.block_manager
+        rids = [f"req{i}" for i in range(B)]
+        for i, r in enumerate(rids):
+            sched.add_request(r, i, L0)
+        # prefill, --prefill-batch prompts at a time
+        for p0 in range(0, B, a.prefill_batch):
+            grp = list(range(p0, min(B, p0 + a.prefill_batch)))
+            inter = [SimpleNamespace(request_id=rids[i], is_prompt=True,
+                                     block_tables={i: list(bm.get_block_table(i))},
+                                     seq_kv_lens={i: bm.get_seq_kv_len(i)}, seq_ids=[i],
+                                     input_tokens=[range(L0)], orig_seq_lens=[L0], seq_lens=[L0],
+                                     query_lens=[L0], context_lens=[0]) for i in grp]
+            meta = self._build(inter, [L0] * len(grp), [L0] * len(grp))
+            T = len(grp) * L0
+            self._layers(self.qp[:T], self.kp[:T], self.vp[:T], meta, self.o_partial_p[:T])
+        # decode
+        L = L0
+        for _ in range(a.output_len):
+            tables, kv_lens = sched.schedule_decode(rids)
+            L += 1
+            trig = self.cfg is not None and self.cfg.evict_method != "inverse_key_l2" \
+                and L > self.budget and L % bs == 0
+            inter, kv_adj = [], []
+            for i in range(B):
+                kvl = kv_lens[i] - (bs if trig else 0)
+                kv_adj.append(kvl)
+                inter.append(SimpleNamespace(request_id=rids[i], is_prompt=False,
+                                             block_tables={i: tables[i]}, seq_kv_lens={i: kvl},
+                                             seq_ids=[i], input_tokens=[(0,)], orig_seq_lens=[L],
+                                             seq_lens=[L], query_lens=[1], context_lens=[kv_lens[i] - 1]))
+            meta = self._build(inter, [L] * B, [1] * B)
+            es = 2
+            nbytes = sum(2 * kvl * self.Hkv * self.D * es + -(-kvl // bs) * 4 for kvl in kv_adj) \
+                + 2 * B * self.Hq * self.D * es
+            self._layers(self.qd, self.kd, self.vd, meta, self.o_partial_d, decode_bytes=nbytes)
+            if self.cfg is not None:
+                sched.commit(self.impls[0].get_rmv_block_idx())
+            used = self.num_blocks - bm.get_num_free_gpu_blocks()
+            self.kv_blocks_peak = max(self.kv_blocks_peak, used)
+        for r in rids:
+            sched.finish_request(r)
+
+
+def cpu_baseline(a, budget):
+    """Reference CPU path (csrc/cpu paged_attention_v1 + reshape_and_cache compiled from the
+    reference's sources, torch CPU SDPA for prefill, composed like the reference's CPU
+    TORCH_SDPA backend) — or the oracle's C port when oracle/_ref is absent — timed on a
+    bounded sample of the same workload and scaled to the whole job."""
+    import torch.nn.functional as F
+    from oracle import pe_oracle
+    ref_lib = os.path.join(ROOT, "oracle", "_ref", "libpe_ref.so")
+    kind = "port"
+    if os.path.exists(ref_lib):
+        try:
+            torch.ops.load_library(ref_lib)
+            kind = "reference"
+        except Exception:
+            kind = "port"
+    cores = torch.get_num_threads() if kind == "reference" else 1
+    B, Hq, Hkv, D, bs = a.num_prompts, a.num_heads, a.num_kv_heads, a.head_size, a.block_size
+    kv_len = (budget + bs // 2) if budget else a.input_len + a.output_len // 2
+    nblk = -(-kv_len // bs)
+    dt = torch.bfloat16
+    sc = D ** -0.5
+    g = torch.Generator().manual_seed(0)
+    nb = B * nblk
+    kc = ((torch.rand(nb, Hkv, D // 8, bs, 8, generator=g) * 2 - 1) * sc).to(dt)
+    vc = ((torch.rand(nb, Hkv, D, bs, generator=g) * 2 - 1) * sc).to(dt)
+    q = ((torch.rand(B, Hq, D, generator=g) * 2 - 1) * sc).to(dt)
+    k1 = ((torch.rand(B, Hkv, D, generator=g) * 2 - 1) * sc).to(dt)
+    bt = torch.randperm(nb, generator=g).to(torch.int32).reshape(B, nblk)
+    lens = torch.full((B,), kv_len, dtype=torch.int32)
+    slots = (bt[:, -1].to(torch.int64) * bs + (kv_len - 1) % bs)
+    out = torch.empty_like(q)
+    n_dec = 3 if kind == "reference" else 1
+
+    def decode_step():
+        if kind == "reference":
+            torch.ops.pe_ref.reshape_and_cache(k1, k1, kc, vc, slots, "auto", 1.0, 1.0)
+            torch.ops.pe_ref.paged_attention_v1(out, q, kc, vc, Hkv, sc, bt, lens, bs, kv_len, None,
+                                                "auto", 1.0, 1.0, 0, 0, 0, 64, 0)
+        else:
+            pe_oracle.reshape_and_cache(k1, k1, kc, vc, slots)
+            pe_oracle.paged_attention(q[:4], kc, vc, bt[:4], lens[:4], sc)
+
+    decode_step()
+    t0 = time.perf_counter()
+    for _ in range(n_dec):
+        decode_step()
+    t_dec = (time.perf_counter() - t0) / n_dec
+    if kind == "port":
+        t_dec *= B / 4.0
+    # prefill: one prompt, one layer, torch CPU SDPA with GQA expansion as the CPU backend does
+    Lp = a.input_len
+    qp = torch.rand(1, Hq, Lp, D, generator=g).to(dt)
+    kp = torch.rand(1, Hkv, Lp, D, generator=g).to(dt).repeat_interleave(Hq // Hkv, dim=1)
+    t0 = time.perf_counter()
+    F.scaled_dot_product_attention(qp, kp, kp, is_causal=True, scale=sc)
+    t_pre = time.perf_counter() - t0
+    t_job = a.layers * (t_pre * B + t_dec * a.output_len)
+    return {
+        "value": round(B * a.output_len / t_job, 3), "unit": "output tok/s (attention path only)",
+        "cores": cores, "kind": kind,
+        "sample": f"1 layer: {n_dec} decode steps (KV write + paged_attention_v1, batch "
+                  f"{B if kind == 'reference' else 4}, kv {kv_len}) + SDPA prefill of 1 prompt of {Lp}; "
+                  f"scaled to {a.layers} layers x ({B} prompts + {a.output_len} steps); no eviction logic "
+                  "(the reference's CPU backend has none)"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    n_gpus = world
+    tp = a.mode == "tp" and world > 1
+    import vllm_paged_compression_amd as pkg
+    pkg.load_library()
+    wl = Workload(a, dev, world if tp else 1, rank if tp else 0, dist.group.WORLD if tp else None)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        wl.generate()
+    sync()
+    wl.timing_on = True
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        wl.generate()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    replicas = 1 if (tp or world == 1) else world
+    total_tokens = a.num_prompts * a.output_len * a.steps * replicas
+    value = total_tokens / dt
+
+    # decode kernel: measured launch durations -> achieved algorithmic bandwidth
+    durs = [s.elapsed_time(e) * 1e-3 for s, e, _ in wl.timed]   # seconds
+    byts = [b for _, _, b in wl.timed]
+    roof = None
+    if durs:
+        avg_t = sum(durs) / len(durs)
+        avg_b = sum(byts) / len(byts)
+        ach = avg_b / avg_t / 1e9
+        roof = {"bound": "hbm", "kernel": "paged_decode_mfma_kernel", "achieved": round(ach, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                "traffic": None, "avg_launch_us": round(avg_t * 1e6, 2),
+                "algorithmic_bytes_per_launch": int(avg_b), "launches_timed": len(durs)}
+    es = 2
+    blk_bytes = 2 * a.block_size * a.num_kv_heads * a.head_size * es * a.layers
+    full_blocks = a.num_prompts * wl.blocks_per_seq_full
+    kv = {"kv_gb_held_peak": round(wl.kv_blocks_peak * blk_bytes / 2 ** 30, 3),
+          "kv_gb_without_eviction": round(full_blocks * blk_bytes / 2 ** 30, 3)}
+    kv["kv_gb_saved"] = round(kv["kv_gb_without_eviction"] - kv["kv_gb_held_peak"], 3)
+    out = {
+        "metric": "output tok/s + KV GB saved, Llama-3-8B 1k->100 @25/50% evict, 1-8 MI355X",
+        "value": round(value, 2), "unit": "output tok/s (attention hot path)",
+        "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
+        "scaling": "strong" if tp else "weak", "vs_baseline": None, "dtype": "bf16",
+        "data": "synthetic",
+        "config": {
+            "workload": f"Llama-3-8B attention geometry (Hq {a.num_heads}, Hkv {a.num_kv_heads}, D "
+                        f"{a.head_size}, {a.layers} layers), block {a.block_size}, {a.num_prompts} "
+                        f"requests {a.input_len}->{a.output_len}, "
+                        + (f"{'budget ' + str(wl.budget)} ({a.evict:.0%} eviction), prompt "
+                           f"{a.prompt_evict_method} / decode {a.decode_evict_method}"
+                           if wl.cfg is not None else "no eviction"),
+            "step": "one full generation of the batch through prefill + decode attention of all layers",
+            "parallelism": (f"tp{world}" if tp else f"dp{world}") if world > 1 else "single",
+            "oproj_allreduce": bool(wl.allreduce), **kv},
+    }
+    if roof is not None:
+        out["roofline"] = roof
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(a, wl.budget)
+        except Exception as e:  # the baseline never decides the run
+            out["cpu_baseline"] = {"value": None, "error": repr(e)}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -394,8 +394,11 @@ class PagedEvictImpl(_ImplBase):
         if self.cache_config is not None and self.cache_config.paged_evict_config is not None:
             self.enabled_paged_eviction = True
             self.paged_evict_config = self.cache_config.paged_evict_config
+            # README-era command lines name the prompt and the decode method separately
+            # (--prompt-evict-method / --decode-evict-method); HEAD has one evict_method for both
+            prompt_method = kwargs.get("prompt_evict_method") or self.paged_evict_config.evict_method
             self.kv_cache_pruner = KVCachePruner(
-                self.paged_evict_config.cache_prune_type, self.paged_evict_config.evict_method,
+                self.paged_evict_config.cache_prune_type, prompt_method,
                 self.cache_config.block_size, self.paged_evict_config.cache_budget,
                 self.paged_evict_config.initial_blocks,
                 cross_head_compat=self.compat.prompt_prune_cross_head)
@@ -405,6 +408,7 @@ class PagedEvictImpl(_ImplBase):
         random.seed(1234)  # the reference seeds the global RNG in every impl (:796)
         self.reqids_mapping_rmv_blockIdx: Dict[int, Tuple[str, int]] = {}
         self._pending_rmv: Optional[torch.Tensor] = None
+        self._pending_reqs: Optional[List[str]] = None
         self._score_table: Optional[DeviceScoreTable] = None
         self.max_num_seqs = int(kwargs.get("max_num_seqs", 256))
         self.max_blocks_per_seq = int(kwargs.get("max_blocks_per_seq", 4096))
@@ -415,9 +419,8 @@ class PagedEvictImpl(_ImplBase):
         if self._pending_rmv is not None:
             rmv = self._pending_rmv.cpu().tolist()
             self._pending_rmv = None
-            self.reqids_mapping_rmv_blockIdx = {
-                i: (self.block_l2norm_mgr.get_reqid_and_seqid(i)[0], r)
-                for i, r in enumerate(rmv) if r >= 0}
+            reqs = self._pending_reqs
+            self.reqids_mapping_rmv_blockIdx = {i: (reqs[i], r) for i, r in enumerate(rmv) if r >= 0}
         return self.reqids_mapping_rmv_blockIdx
 
     def forward(self, query: torch.Tensor, key: torch.Tensor, value: torch.Tensor,
@@ -432,6 +435,16 @@ class PagedEvictImpl(_ImplBase):
         self.reqids_mapping_rmv_blockIdx = {}
         self._pending_rmv = None
         T = query.shape[0]
+        # decode layers after the first of a step: metadata already validated, decision taken
+        launcher = attn_metadata._pe_step.get("launcher")
+        if launcher is not None and launcher.matches(query, key, value, kv_cache):
+            dec = attn_metadata._pe_step.get("decode")
+            if dec is not None:
+                self._pending_rmv, self._pending_reqs = dec["rmv"], dec.get("req_ids")
+                self.reqids_mapping_rmv_blockIdx = dec["host_rmv"] or {}
+            o = torch.empty_like(query) if output is None else output
+            launcher.run(query, key, value, kv_cache, o)
+            return o
         query = query.view(-1, self.num_heads, self.head_size)
         key = key.view(-1, self.num_kv_heads, self.head_size)
         value = value.view(-1, self.num_kv_heads, self.head_size)
@@ -446,14 +459,19 @@ class PagedEvictImpl(_ImplBase):
                 and self.enabled_paged_eviction:
             raise NotImplementedError(
                 "Chunked prefill is not supported when paged eviction is enabled.")
-        if self.enabled_paged_eviction and not is_profile_run:
+        if self.enabled_paged_eviction and not is_profile_run and (
+                self.compat.per_layer_decision or self.layer_idx <= 0
+                or "mgr" not in attn_metadata._pe_step):
+            # only the deciding layer tracks the batch composition
             self.block_l2norm_mgr.update_reqs(attn_metadata.reqid_mapping_blocktables)
+            attn_metadata._pe_step.setdefault("mgr", self.block_l2norm_mgr)
 
         if (pm := attn_metadata.prefill_metadata) is not None:
             self._forward_prefill(out, query, key, value, key_cache, value_cache, attn_metadata, pm,
                                   is_profile_run)
         if (dm := attn_metadata.decode_metadata) is not None:
-            self._forward_decode(out, query, key, value, key_cache, value_cache, attn_metadata, dm)
+            self._forward_decode(out, query, key, value, key_cache, value_cache, attn_metadata, dm,
+                                 kv_cache)
         return out.view(T, self.num_heads * self.head_size)
 
     # ------------------------------------------------------------------------------ prefill
@@ -554,7 +572,8 @@ class PagedEvictImpl(_ImplBase):
         table.retain_only(list(self.block_l2norm_mgr.flat_sequence_map))
 
     # ------------------------------------------------------------------------------- decode
-    def _forward_decode(self, out, query, key, value, key_cache, value_cache, meta, dm) -> None:
+    def _forward_decode(self, out, query, key, value, key_cache, value_cache, meta, dm,
+                        kv_cache=None) -> None:
         n0 = meta.num_prefill_tokens
         q, k, v = query[n0:], key[n0:], value[n0:]
         block_tables = dm.block_tables
@@ -566,13 +585,30 @@ class PagedEvictImpl(_ImplBase):
             if dec["tables"] is not None:
                 block_tables = dec["tables"]
             zero_slots = dec["zero_slots"]
-            self._pending_rmv = dec["rmv"]
+            self._pending_rmv, self._pending_reqs = dec["rmv"], dec.get("req_ids")
             self.reqids_mapping_rmv_blockIdx = dec["host_rmv"] or {}
+        # every layer of the step launches with the same metadata: validate once, then reuse
+        step = meta._pe_step
+        launcher = step.get("launcher")
+        if (launcher is not None and launcher.tables is block_tables and launcher.zero is zero_slots
+                and kv_cache is not None and launcher.matches(q, k, v, kv_cache)):
+            launcher.run(q, k, v, kv_cache, out[n0:])
+            return
         PagedAttention.write_to_paged_cache(k, v, key_cache, value_cache, dm.slot_mapping,
                                             self.kv_cache_dtype, 1.0, 1.0, zero_slots=zero_slots)
         PagedAttention.forward_decode(q, key_cache, value_cache, block_tables, seq_lens_arg,
                                       dm.max_decode_seq_len, self.kv_cache_dtype, self.num_kv_heads,
                                       self.scale, None, 1.0, 1.0, output=out[n0:])
+        if kv_cache is not None and n0 == 0 and not self.compat.per_layer_decision:
+            try:
+                launcher = ops.DecodeLayerLauncher(q, k, v, kv_cache, self.num_heads, self.num_kv_heads,
+                                                   self.head_size, dm.slot_mapping, zero_slots,
+                                                   block_tables, seq_lens_arg, dm.max_decode_seq_len,
+                                                   self.scale)
+                launcher.tables, launcher.zero = block_tables, zero_slots
+                step["launcher"] = launcher
+            except RuntimeError:
+                step["launcher"] = None
 
     def _decode_decision(self, meta, dm, value_cache) -> Dict[str, Any]:
         """Eviction decision of this decode step: taken by the first layer that runs and reused
@@ -587,8 +623,10 @@ class PagedEvictImpl(_ImplBase):
         dev = dm.block_tables.device
         over = [L > cfg.cache_budget for L in seq_lens]
         trig = [o and L % bs == 0 for o, L in zip(over, seq_lens)]
-        dec: Dict[str, Any] = {"rmv": None, "tables": None, "zero_slots": None, "host_rmv": None}
-        mgr = self.block_l2norm_mgr
+        mgr = step.get("mgr", self.block_l2norm_mgr)
+        dec: Dict[str, Any] = {"rmv": None, "tables": None, "zero_slots": None, "host_rmv": None,
+                               "req_ids": [mgr.get_reqid_and_seqid(i)[0] for i in range(len(seq_lens))]
+                               if any(trig) else None}
         # width of the compacted table: the longest row once the victims are gone (the
         # reference always uses M-1 and so can cut a full-length row that evicts nothing)
         M = dm.block_tables.shape[1]

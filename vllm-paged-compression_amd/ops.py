@@ -382,6 +382,82 @@ def evict_select_compact(block_tables: torch.Tensor, seq_lens: torch.Tensor,
     return rmv, out_tables, zero
 
 
+# --------------------------------------------------------------------------------------
+class DecodeLayerLauncher:
+    """Pre-validated launcher of one decode layer (KV write + paged attention).
+
+    All layers of a decode step share the step's metadata (slot mapping, block tables, kv
+    lengths) and the shapes of q/k/v/kv_cache; validating them once per step and re-using the
+    argument list keeps the per-layer host cost to two foreign calls, which matters because a
+    decode layer is only tens of microseconds of GPU time.  ``matches`` tells whether a layer's
+    tensors have the signature the launcher was built for."""
+
+    def __init__(self, query, key, value, kv_cache, num_heads, num_kv_heads, head_size,
+                 slot_mapping, zero_slots, block_tables, seq_lens, max_seq_len, scale):
+        dev = _need_gpu(query, key, value, kv_cache, slot_mapping, zero_slots, block_tables, seq_lens)
+        lib = _lib.load()
+        self._lib = lib
+        self.sig = self.signature(query, key, value, kv_cache)
+        es = kv_cache.element_size()
+        if kv_cache.dim() != 3 or kv_cache.shape[0] != 2 or not kv_cache.is_contiguous():
+            raise RuntimeError("kv_cache must be a contiguous [2, num_blocks, block_elems] tensor")
+        nb = kv_cache.shape[1]
+        bs = kv_cache.shape[2] // (num_kv_heads * head_size)
+        if slot_mapping.dtype != torch.int64 or block_tables.dtype != torch.int32 \
+                or seq_lens.dtype != torch.int32:
+            raise RuntimeError("decode launcher: slot_mapping int64, block_tables/seq_lens int32 expected")
+        if not (slot_mapping.is_contiguous() and block_tables.is_contiguous() and seq_lens.is_contiguous()):
+            raise RuntimeError("decode launcher: metadata tensors must be contiguous")
+        S = query.shape[0]
+        if block_tables.shape[0] != S or seq_lens.numel() != S or slot_mapping.numel() != S:
+            raise RuntimeError("decode launcher: metadata does not match the batch")
+        if query.dtype != kv_cache.dtype or key.dtype != kv_cache.dtype or value.dtype != kv_cache.dtype:
+            raise RuntimeError("decode launcher: dtype mismatch")
+        self.v_off = kv_cache.stride(0) * es
+        dt = _dtype_code(query)
+        stream = _stream(dev)
+        nz = 0 if zero_slots is None else zero_slots.numel()
+        need = lib.pe_paged_decode_workspace_bytes(S, num_heads, num_kv_heads, head_size, bs, max_seq_len)
+        ws = _workspace(dev, need)
+        self._keep = (slot_mapping, zero_slots, block_tables, seq_lens, ws)
+        self._rc_tail = (_p(slot_mapping), S, key.stride(0), value.stride(0), None, 0, _p(zero_slots), nz,
+                         num_kv_heads, head_size, bs, nb, dt, stream)
+        kv_head_stride = head_size * bs
+        self._pa_tail = (_p(block_tables), _p(seq_lens), None, S, num_heads, num_kv_heads, head_size, bs,
+                         block_tables.shape[1], query.stride(0), kv_cache.stride(1), kv_head_stride,
+                         float(scale), int(max_seq_len), dt, _p(ws), 0 if ws is None else ws.numel(), stream)
+
+    @staticmethod
+    def signature(query, key, value, kv_cache):
+        return (query.shape[0], query.stride(0), key.stride(0), value.stride(0), kv_cache.shape,
+                kv_cache.dtype, query.dtype, query.device, query.numel(), key.numel())
+
+    def matches(self, query, key, value, kv_cache) -> bool:
+        return self.sig == self.signature(query, key, value, kv_cache)
+
+    # measurement hook: when set to a list, run() brackets the attention launch with events on
+    # the launch stream and appends (start, end)
+    event_sink = None
+
+    def run(self, query, key, value, kv_cache, out) -> None:
+        kc = kv_cache.data_ptr()
+        vc = kc + self.v_off
+        lib = self._lib
+        _lib.check(lib.pe_reshape_and_cache(key.data_ptr(), value.data_ptr(), kc, vc, *self._rc_tail),
+                   "reshape_and_cache")
+        sink = DecodeLayerLauncher.event_sink
+        if sink is None:
+            _lib.check(lib.pe_paged_decode(out.data_ptr(), query.data_ptr(), kc, vc, *self._pa_tail),
+                       "paged_attention")
+        else:
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            _lib.check(lib.pe_paged_decode(out.data_ptr(), query.data_ptr(), kc, vc, *self._pa_tail),
+                       "paged_attention")
+            e.record()
+            sink.append((s, e))
+
+
 # -------------------------------------------------------------------------------------- torch.library
 _registered = False
 
