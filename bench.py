@@ -310,9 +310,22 @@ def main():
         avg_t = sum(durs) / len(durs)
         avg_b = sum(byts) / len(byts)
         ach = avg_b / avg_t / 1e9
+        # HBM bytes per launch from the PMC passes kept under profiles/ (FETCH_SIZE x2 per the
+        # gfx950 correction + WRITE_SIZE), as a ratio to the algorithmic bytes of the profiled
+        # launch; applied only to the shape it was measured on
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_decode_pmc.json")))
+            sh = pmc["shape"]
+            if (sh["batch"], sh["num_heads"], sh["num_kv_heads"], sh["head_size"], sh["block_size"]) == \
+                    (a.num_prompts, wl.Hq, wl.Hkv, a.head_size, a.block_size) and \
+                    abs(avg_b / pmc["algorithmic_bytes_per_launch"] - 1.0) < 0.05:
+                traffic = int(avg_b * pmc["traffic_over_algorithmic"])
+        except Exception:
+            traffic = None
         roof = {"bound": "hbm", "kernel": "paged_decode_mfma_kernel", "achieved": round(ach, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                "traffic": None, "avg_launch_us": round(avg_t * 1e6, 2),
+                "traffic": traffic, "avg_launch_us": round(avg_t * 1e6, 2),
                 "algorithmic_bytes_per_launch": int(avg_b), "launches_timed": len(durs)}
     es = 2
     blk_bytes = 2 * a.block_size * a.num_kv_heads * a.head_size * es * a.layers
