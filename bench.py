@@ -61,7 +61,6 @@ def parse():
     ap.add_argument("--no-oproj-allreduce", action="store_true",
                     help="tp: skip the all-reduce of the [tokens, hidden] o_proj output after each layer")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--time-layer", type=int, default=1, help="layer whose decode launches are event-timed")
     return ap.parse_args()
 
 
@@ -125,26 +124,24 @@ class Workload:
         return self.backend.make_metadata_builder(ib).build(seq_lens, q_lens, -1, len(seq_lens))
 
     def _layers(self, q, k, v, meta, o_partial, decode_bytes=None):
+        """All layers of one step.  For decode steps of the timed region, layers 1..L-1 (layer 0
+        also carries the step's eviction launch) are bracketed by one pair of HIP events on the
+        launch stream: every launch between them is the decode-attention kernel, so the span
+        divided by the launch count is that kernel's average launch duration."""
         from vllm_paged_compression_amd import parallel
+        span = (decode_bytes is not None and self.timing_on and not self.allreduce
+                and len(self.impls) > 2)
         for li, impl in enumerate(self.impls):
-            if decode_bytes is not None and self.timing_on and li == self.a.time_layer % len(self.impls):
-                self._timed_forward(impl, q, k, v, self.kv[li], meta, decode_bytes)
-            else:
-                impl.forward(q, k, v, self.kv[li], meta)
+            if span and li == 1:
+                s_ev = torch.cuda.Event(enable_timing=True)
+                s_ev.record()
+            impl.forward(q, k, v, self.kv[li], meta)
             if self.allreduce:
                 parallel.all_reduce_sum(o_partial, self.tp_group)
-
-    def _timed_forward(self, impl, q, k, v, kv, meta, nbytes):
-        """Event-brackets only the decode-attention launch inside forward()."""
-        from vllm_paged_compression_amd import ops
-        sink = []
-        ops.DecodeLayerLauncher.event_sink = sink
-        try:
-            impl.forward(q, k, v, kv, meta)
-        finally:
-            ops.DecodeLayerLauncher.event_sink = None
-        for s, e in sink:
-            self.timed.append((s, e, nbytes))
+        if span:
+            e_ev = torch.cuda.Event(enable_timing=True)
+            e_ev.record()
+            self.timed.append((s_ev, e_ev, decode_bytes, len(self.impls) - 1))
 
     # ---- one generation ---------------------------------------------------------------------
     def generate(self):
@@ -303,8 +300,8 @@ def main():
     value = total_tokens / dt
 
     # decode kernel: measured launch durations -> achieved algorithmic bandwidth
-    durs = [s.elapsed_time(e) * 1e-3 for s, e, _ in wl.timed]   # seconds
-    byts = [b for _, _, b in wl.timed]
+    durs = [s.elapsed_time(e) * 1e-3 / n for s, e, _, n in wl.timed]   # seconds per launch
+    byts = [b for _, _, b, _ in wl.timed]
     roof = None
     if durs:
         avg_t = sum(durs) / len(durs)
@@ -326,7 +323,9 @@ def main():
         roof = {"bound": "hbm", "kernel": "paged_decode_mfma_kernel", "achieved": round(ach, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "avg_launch_us": round(avg_t * 1e6, 2),
-                "algorithmic_bytes_per_launch": int(avg_b), "launches_timed": len(durs)}
+                "algorithmic_bytes_per_launch": int(avg_b),
+                "launches_timed": sum(n for _, _, _, n in wl.timed),
+                "includes": "fused KV write of the step's token (pe_decode_step)"}
     es = 2
     blk_bytes = 2 * a.block_size * a.num_kv_heads * a.head_size * es * a.layers
     full_blocks = a.num_prompts * wl.blocks_per_seq_full

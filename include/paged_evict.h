@@ -116,6 +116,28 @@ int pe_paged_decode(void* out, const void* query, const void* key_cache,
                     int64_t kv_head_stride, float scale, int max_seq_len, int dtype,
                     void* workspace, int64_t workspace_bytes, void* stream);
 
+/* One decode layer in one launch: the KV write of this step's token (what
+ * pe_reshape_and_cache does for a decode batch: key/value [num_seqs, num_kv_heads, head_size],
+ * slot_mapping int64[num_seqs], negative = skip) fused in front of the attention of
+ * pe_paged_decode.  Replaces the reshape_and_cache + paged_attention_v1/v2 pair that the
+ * reference issues per layer in its decode branch
+ * (vllm/attention/backends/torch_cuda_sdpa.py:936,947,1049-1062).  Requirements beyond
+ * pe_paged_decode's: the shape must be one pe_paged_decode_supports_fused_write() accepts, and
+ * slot_mapping[s] must lie in the last block of sequence s's table (it does for a decode step:
+ * slot = table[-1]*block_size + offset), because the write is ordered only against the reads
+ * of the workgroup that owns that block.  seq_lens counts the new token. */
+int pe_paged_decode_supports_fused_write(int num_heads, int num_kv_heads, int head_size,
+                                         int block_size, int dtype);
+int pe_decode_step(void* out, const void* query, const void* new_key, const void* new_value,
+                   void* key_cache, void* value_cache, const int64_t* slot_mapping,
+                   const int32_t* block_tables, const int32_t* seq_lens,
+                   const float* alibi_slopes, int num_seqs, int num_heads, int num_kv_heads,
+                   int head_size, int block_size, int64_t num_blocks,
+                   int max_num_blocks_per_seq, int64_t q_stride, int64_t new_k_stride,
+                   int64_t new_v_stride, int64_t kv_block_stride, int64_t kv_head_stride,
+                   float scale, int max_seq_len, int dtype, void* workspace,
+                   int64_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Prefill attention.  Replaces TorchCUDASDPABackendImpl._run_sdpa_forward
  * (vllm/attention/backends/torch_cuda_sdpa.py:1069-1127): per request causal attention

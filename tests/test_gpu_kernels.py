@@ -529,3 +529,37 @@ def test_prompt_token_select_batch_with_ties(ops, oracle, method, dtype):
     oracle.reshape_and_cache(ek, ev, kc, vc, slots)
     ops.reshape_and_cache(k.cuda(), v.cuda(), kc_d, vc_d, slots.cuda(), src_index=idx)
     assert torch.equal(kc_d.cpu(), kc) and torch.equal(vc_d.cpu(), vc)
+
+
+# ------------------------------------------------------------------ fused decode step
+@pytest.mark.parametrize("Hq,Hkv,D,dtype", [(32, 8, 128, torch.bfloat16), (12, 12, 64, torch.float16),
+                                            (8, 1, 128, torch.bfloat16)])
+@pytest.mark.parametrize("splits", [0, 3])
+def test_decode_step_fused_write(ops, oracle, Hq, Hkv, D, dtype, splits, monkeypatch):
+    """One launch (KV write + attention) == reshape_and_cache followed by paged attention:
+    cache bytes identical, outputs within the kernel tolerance."""
+    if splits:
+        monkeypatch.setenv("PE_DECODE_SPLITS", str(splits))
+    g = torch.Generator().manual_seed(Hq + D)
+    bs, nb = 16, 400
+    lens = [1, 16, 17, 32, 33, 700, 784, 2000]       # kv length including the new token
+    S = len(lens)
+    sc = D ** -0.5
+    kc, vc = make_cache(nb, Hkv, D, bs, dtype, g)
+    q = ((torch.rand(S, Hq, D, generator=g) * 2 - 1) * sc).to(dtype)
+    k = ((torch.rand(S, Hkv, D, generator=g) * 2 - 1) * sc).to(dtype)
+    v = ((torch.rand(S, Hkv, D, generator=g) * 2 - 1) * sc).to(dtype)
+    M = max(lens) // bs + 1
+    bt = torch.stack([torch.randperm(nb, generator=g)[:M] for _ in range(S)]).to(torch.int32)
+    slots = torch.tensor([int(bt[i, (L - 1) // bs]) * bs + (L - 1) % bs for i, L in enumerate(lens)],
+                         dtype=torch.int64)
+    slots[1] = -1                                     # padding token: nothing written
+    lens_t = torch.tensor(lens, dtype=torch.int32)
+    kc_d, vc_d = kc.cuda(), vc.cuda()
+    out = torch.empty_like(q, device="cuda")
+    ops.decode_step(out, q.cuda(), k.cuda(), v.cuda(), kc_d, vc_d, slots.cuda(), Hkv, sc, bt.cuda(),
+                    lens_t.cuda(), bs, max(lens))
+    oracle.reshape_and_cache(k, v, kc, vc, slots)
+    ref = oracle.paged_attention(q, kc, vc, bt, lens_t, sc)
+    assert torch.equal(kc_d.cpu(), kc) and torch.equal(vc_d.cpu(), vc)
+    torch.testing.assert_close(out.cpu().float(), ref.float(), atol=ATOL[dtype], rtol=RTOL[dtype])

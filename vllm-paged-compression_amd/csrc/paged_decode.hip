@@ -49,7 +49,11 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void paged_decode_mfma_kernel(
     const int32_t* __restrict__ block_tables, const int32_t* __restrict__ seq_lens,
     const float* __restrict__ alibi_slopes, int num_heads, int num_kv_heads,
     int max_num_blocks_per_seq, int64_t q_stride, int64_t kv_block_stride,
-    int64_t kv_head_stride, float scale, int num_splits) {
+    int64_t kv_head_stride, float scale, int num_splits, const T* __restrict__ new_key,
+    const T* __restrict__ new_value, const int64_t* __restrict__ new_slots, int64_t new_k_stride,
+    int64_t new_v_stride, int64_t num_slots, T* key_cache_w, T* value_cache_w) {
+  // key_cache_w / value_cache_w: the same caches through non-restrict pointers, used only by
+  // the fused KV write (the written slot is never loaded by this launch).
   using TR = Traits<T>;
   using vec8 = typename TR::vec8;
   using vec4 = typename TR::vec4;
@@ -69,7 +73,17 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void paged_decode_mfma_kernel(
 
   // a length beyond what the table row can address is clamped (never read past the row)
   const int seq_len = min(seq_lens[seq], max_num_blocks_per_seq * BS);
-  const int n_blocks = (seq_len + BS - 1) / BS;
+  // Fused KV write: the step's new token (position seq_len-1) is taken from new_key/new_value
+  // directly and only the seq_len-1 older tokens are read from the cache, so the store of the
+  // new row into the cache needs no ordering against this kernel's loads.
+  bool has_new = false;
+  int64_t new_slot = -1;
+  if (new_key != nullptr && seq_len > 0) {
+    new_slot = new_slots[seq];
+    has_new = new_slot >= 0 && new_slot < num_slots;
+  }
+  const int cached_len = has_new ? seq_len - 1 : seq_len;
+  const int n_blocks = (cached_len + BS - 1) / BS;
   const int n_pairs = (n_blocks + 1) / 2;
   const int pairs_per_split = (n_pairs + num_splits - 1) / num_splits;
   const int pair_begin = split * pairs_per_split;
@@ -122,7 +136,8 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void paged_decode_mfma_kernel(
     }
   };
 
-  auto compute = [&](const DecTile<T, HEAD_SIZE>& t, int pair) {
+  // tile tokens are tok_base + b*16 + 4g + r; tokens >= limit are masked
+  auto compute = [&](const DecTile<T, HEAD_SIZE>& t, int tok_base, int limit) {
     f32x4 s[2];
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
@@ -133,12 +148,12 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void paged_decode_mfma_kernel(
     float mx = NEG_BIG;
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-      const int tok0 = (2 * pair + b) * BS + 4 * g;
+      const int tok0 = tok_base + b * BS + 4 * g;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int tok = tok0 + r;
         float x = s[b][r] * scale + slope * (float)(tok - seq_len + 1);
-        x = tok < seq_len ? x : NEG_BIG;
+        x = tok < limit ? x : NEG_BIG;
         s[b][r] = x;
         mx = fmaxf(mx, x);
       }
@@ -162,7 +177,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void paged_decode_mfma_kernel(
     l_run = l_run * alpha + psum;
     // slots past seq_len in the last block may hold anything (NaN included): their V is
     // replaced by zero, as the reference does (attention_kernels.cuh:420-430)
-    const bool tail = (2 * pair + 2) * BS > seq_len;  // wave-uniform
+    const bool tail = tok_base + 2 * BS > limit;  // wave-uniform
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
       acc[dt] *= alpha;
@@ -175,8 +190,8 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void paged_decode_mfma_kernel(
       if (tail) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const int tok = (2 * pair + (j >> 2)) * BS + 4 * g + (j & 3);
-          vf[j] = tok < seq_len ? vf[j] : (T)0.f;
+          const int tok = tok_base + (j >> 2) * BS + 4 * g + (j & 3);
+          vf[j] = tok < limit ? vf[j] : (T)0.f;
         }
       }
       acc[dt] = TR::mfma16(vf, pf, acc[dt]);
@@ -193,11 +208,11 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void paged_decode_mfma_kernel(
       issue(t0, p);
       while (true) {
         if (p + DEC_WAVES < pair_end) issue(t1, p + DEC_WAVES);
-        compute(t0, p);
+        compute(t0, 2 * p * BS, cached_len);
         p += DEC_WAVES;
         if (p >= pair_end) break;
         if (p + DEC_WAVES < pair_end) issue(t0, p + DEC_WAVES);
-        compute(t1, p);
+        compute(t1, 2 * p * BS, cached_len);
         p += DEC_WAVES;
         if (p >= pair_end) break;
       }
@@ -207,8 +222,40 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void paged_decode_mfma_kernel(
     DecTile<T, HEAD_SIZE> t0;
     for (int p = pair_begin + wave; p < pair_end; p += DEC_WAVES) {
       issue(t0, p);
-      compute(t0, p);
+      compute(t0, 2 * p * BS, cached_len);
     }
+  }
+
+  // ---- the step's new token: attention contribution from registers + store into the cache --
+  if (has_new && split == 0 &&
+      wave == ((pair_end > pair_begin ? pair_end - pair_begin : 0) % DEC_WAVES)) {
+    const T* ksrc = new_key + (int64_t)seq * new_k_stride + (int64_t)kvh * HEAD_SIZE;
+    const T* vsrc = new_value + (int64_t)seq * new_v_stride + (int64_t)kvh * HEAD_SIZE;
+    DecTile<T, HEAD_SIZE> tn;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      u32x4 raw = {0u, 0u, 0u, 0u};
+      if (hc == 0) raw = *reinterpret_cast<const u32x4*>(ksrc + 32 * ks + 8 * g);  // row = token 0
+      tn.k[0][ks] = __builtin_bit_cast(vec8, raw);
+      tn.k[1][ks] = __builtin_bit_cast(vec8, u32x4{0u, 0u, 0u, 0u});
+    }
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      vec4 v4 = {(T)0.f, (T)0.f, (T)0.f, (T)0.f};
+      if (g == 0) v4[0] = vsrc[16 * dt + hc];  // k-slot (g=0, j=0) = token 0 of the tile
+      tn.v[0][dt] = v4;
+      tn.v[1][dt] = vec4{(T)0.f, (T)0.f, (T)0.f, (T)0.f};
+    }
+    compute(tn, seq_len - 1, seq_len);
+    // store the row into its cache slot (same bytes pe_reshape_and_cache writes)
+    const int64_t blk = new_slot / BS;
+    const int off = (int)(new_slot % BS);
+    T* kdst = key_cache_w + blk * kv_block_stride + (int64_t)kvh * kv_head_stride;
+    T* vdst = value_cache_w + blk * kv_block_stride + (int64_t)kvh * kv_head_stride;
+    for (int c = lane; c < HEAD_SIZE / 8; c += 64)
+      *reinterpret_cast<u32x4*>(kdst + (c * BS + off) * 8) =
+          *reinterpret_cast<const u32x4*>(ksrc + c * 8);
+    for (int d = lane; d < HEAD_SIZE; d += 64) vdst[d * BS + off] = vsrc[d];
   }
 
   // ---- merge the 4 lane groups' sums, then the waves through LDS -------------------
@@ -398,12 +445,14 @@ int64_t pe_paged_decode_workspace_bytes(int num_seqs, int num_heads, int num_kv_
   return (int64_t)max_splits * num_seqs * num_heads * pe::ws_stride(head_size) * 4;
 }
 
-int pe_paged_decode(void* out, const void* query, const void* key_cache, const void* value_cache,
-                    const int32_t* block_tables, const int32_t* seq_lens,
-                    const float* alibi_slopes, int num_seqs, int num_heads, int num_kv_heads,
-                    int head_size, int block_size, int max_num_blocks_per_seq, int64_t q_stride,
-                    int64_t kv_block_stride, int64_t kv_head_stride, float scale, int max_seq_len,
-                    int dtype, void* workspace, int64_t workspace_bytes, void* stream) {
+static int decode_impl(void* out, const void* query, const void* key_cache, const void* value_cache,
+                       const int32_t* block_tables, const int32_t* seq_lens,
+                       const float* alibi_slopes, int num_seqs, int num_heads, int num_kv_heads,
+                       int head_size, int block_size, int max_num_blocks_per_seq, int64_t q_stride,
+                       int64_t kv_block_stride, int64_t kv_head_stride, float scale, int max_seq_len,
+                       int dtype, void* workspace, int64_t workspace_bytes, void* stream,
+                       const void* new_key, const void* new_value, const int64_t* new_slots,
+                       int64_t new_k_stride, int64_t new_v_stride, int64_t num_slots) {
   using namespace pe;
   PE_REQUIRE(num_seqs >= 0, PE_ERR_INVALID_ARG, "negative num_seqs");
   if (num_seqs == 0) return PE_OK;
@@ -438,7 +487,8 @@ int pe_paged_decode(void* out, const void* query, const void* key_cache, const v
                      ws, (const T*)query, (const T*)key_cache, (const T*)value_cache,            \
                      block_tables, seq_lens, alibi_slopes, num_heads, num_kv_heads,              \
                      max_num_blocks_per_seq, q_stride, kv_block_stride, kv_head_stride, scale,   \
-                     splits)
+                     splits, (const T*)new_key, (const T*)new_value, new_slots, new_k_stride,     \
+                     new_v_stride, num_slots, (T*)key_cache, (T*)value_cache)
     PE_DISPATCH_16(dtype, T, {
       if (head_size == 64) PE_LAUNCH_DEC(T, 64);
       else if (head_size == 128) PE_LAUNCH_DEC(T, 128);
@@ -481,6 +531,46 @@ int pe_paged_decode(void* out, const void* query, const void* key_cache, const v
   PE_DISPATCH_ALL(dtype, T, PE_LAUNCH_GEN(T));
 #undef PE_LAUNCH_GEN
   return check_launch("paged_decode_generic");
+}
+
+int pe_paged_decode(void* out, const void* query, const void* key_cache, const void* value_cache,
+                    const int32_t* block_tables, const int32_t* seq_lens,
+                    const float* alibi_slopes, int num_seqs, int num_heads, int num_kv_heads,
+                    int head_size, int block_size, int max_num_blocks_per_seq, int64_t q_stride,
+                    int64_t kv_block_stride, int64_t kv_head_stride, float scale, int max_seq_len,
+                    int dtype, void* workspace, int64_t workspace_bytes, void* stream) {
+  return decode_impl(out, query, key_cache, value_cache, block_tables, seq_lens, alibi_slopes,
+                     num_seqs, num_heads, num_kv_heads, head_size, block_size,
+                     max_num_blocks_per_seq, q_stride, kv_block_stride, kv_head_stride, scale,
+                     max_seq_len, dtype, workspace, workspace_bytes, stream, nullptr, nullptr,
+                     nullptr, 0, 0, 0);
+}
+
+int pe_paged_decode_supports_fused_write(int num_heads, int num_kv_heads, int head_size,
+                                         int block_size, int dtype) {
+  return pe::mfma_path_ok(num_heads, num_kv_heads, head_size, block_size, dtype, 8, 8, 8) ? 1 : 0;
+}
+
+int pe_decode_step(void* out, const void* query, const void* new_key, const void* new_value,
+                   void* key_cache, void* value_cache, const int64_t* slot_mapping,
+                   const int32_t* block_tables, const int32_t* seq_lens, const float* alibi_slopes,
+                   int num_seqs, int num_heads, int num_kv_heads, int head_size, int block_size,
+                   int64_t num_blocks, int max_num_blocks_per_seq, int64_t q_stride,
+                   int64_t new_k_stride, int64_t new_v_stride, int64_t kv_block_stride,
+                   int64_t kv_head_stride, float scale, int max_seq_len, int dtype, void* workspace,
+                   int64_t workspace_bytes, void* stream) {
+  using namespace pe;
+  PE_REQUIRE(num_seqs == 0 || (new_key && new_value && slot_mapping), PE_ERR_INVALID_ARG,
+             "decode_step: null new_key/new_value/slot_mapping");
+  PE_REQUIRE(new_k_stride % 8 == 0 && new_v_stride % 8 == 0 &&
+                 (((uintptr_t)new_key | (uintptr_t)new_value) % 16 == 0),
+             PE_ERR_INVALID_ARG, "decode_step: new key/value rows must be 16-byte aligned");
+  PE_REQUIRE(num_blocks > 0, PE_ERR_INVALID_ARG, "decode_step: bad num_blocks");
+  return decode_impl(out, query, key_cache, value_cache, block_tables, seq_lens, alibi_slopes,
+                     num_seqs, num_heads, num_kv_heads, head_size, block_size,
+                     max_num_blocks_per_seq, q_stride, kv_block_stride, kv_head_stride, scale,
+                     max_seq_len, dtype, workspace, workspace_bytes, stream, new_key, new_value,
+                     slot_mapping, new_k_stride, new_v_stride, num_blocks * block_size);
 }
 
 }  // extern "C"

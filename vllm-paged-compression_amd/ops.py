@@ -382,6 +382,38 @@ def evict_select_compact(block_tables: torch.Tensor, seq_lens: torch.Tensor,
     return rmv, out_tables, zero
 
 
+def decode_step(out, query, key, value, key_cache, value_cache, slot_mapping, num_kv_heads, scale,
+                block_tables, seq_lens, block_size, max_seq_len, alibi_slopes=None) -> None:
+    """KV write of a decode batch + paged attention in ONE launch (see pe_decode_step).  query
+    [S, Hq, D], key/value [S, Hkv, D], slot_mapping int64[S] (each slot in its sequence's last
+    block), seq_lens int32[S] counting the new token."""
+    dev = _need_gpu(out, query, key, value, key_cache, value_cache, slot_mapping, block_tables, seq_lens)
+    S, Hq, D = query.shape
+    nb = value_cache.shape[0]
+    if key.shape != (S, num_kv_heads, D) or value.shape != key.shape:
+        raise RuntimeError("decode_step: key/value must be [num_seqs, num_kv_heads, head_size]")
+    for t in (query, key, value):
+        if t.stride(2) != 1 or t.stride(1) != D or t.dtype != key_cache.dtype:
+            raise RuntimeError("decode_step: dense rows of the cache dtype expected")
+    if slot_mapping.dtype != torch.int64 or slot_mapping.numel() != S or not slot_mapping.is_contiguous():
+        raise RuntimeError("decode_step: slot_mapping must be contiguous int64[num_seqs]")
+    if block_tables.dtype != torch.int32 or seq_lens.dtype != torch.int32 or \
+            not block_tables.is_contiguous() or not seq_lens.is_contiguous() or not out.is_contiguous():
+        raise RuntimeError("decode_step: int32 contiguous block_tables/seq_lens, contiguous out expected")
+    lib = _lib.load()
+    if not lib.pe_paged_decode_supports_fused_write(Hq, num_kv_heads, D, block_size, _dtype_code(query)):
+        raise RuntimeError("decode_step: shape not supported by the fused kernel; use "
+                           "reshape_and_cache + paged_attention_v1")
+    need = lib.pe_paged_decode_workspace_bytes(S, Hq, num_kv_heads, D, block_size, max_seq_len)
+    ws = _workspace(dev, need)
+    _lib.check(lib.pe_decode_step(
+        _p(out), _p(query), _p(key), _p(value), _p(key_cache), _p(value_cache), _p(slot_mapping),
+        _p(block_tables), _p(seq_lens), _p(alibi_slopes), S, Hq, num_kv_heads, D, block_size, nb,
+        block_tables.shape[1], query.stride(0), key.stride(0), value.stride(0), key_cache.stride(0),
+        key_cache.stride(1), float(scale), int(max_seq_len), _dtype_code(query), _p(ws),
+        0 if ws is None else ws.numel(), _stream(dev)), "decode_step")
+
+
 # --------------------------------------------------------------------------------------
 class DecodeLayerLauncher:
     """Pre-validated launcher of one decode layer (KV write + paged attention).
@@ -426,6 +458,16 @@ class DecodeLayerLauncher:
         self._pa_tail = (_p(block_tables), _p(seq_lens), None, S, num_heads, num_kv_heads, head_size, bs,
                          block_tables.shape[1], query.stride(0), kv_cache.stride(1), kv_head_stride,
                          float(scale), int(max_seq_len), dt, _p(ws), 0 if ws is None else ws.numel(), stream)
+        # one launch per layer (KV write fused into the attention kernel) when nothing has to be
+        # zeroed and the shape runs on the MFMA decode path
+        self.fused = nz == 0 and bool(lib.pe_paged_decode_supports_fused_write(
+            num_heads, num_kv_heads, head_size, bs, dt)) and query.stride(0) % 8 == 0 \
+            and key.stride(0) % 8 == 0 and value.stride(0) % 8 == 0
+        self._fs_tail = (_p(slot_mapping), _p(block_tables), _p(seq_lens), None, S, num_heads,
+                         num_kv_heads, head_size, bs, nb, block_tables.shape[1], query.stride(0),
+                         key.stride(0), value.stride(0), kv_cache.stride(1), kv_head_stride,
+                         float(scale), int(max_seq_len), dt, _p(ws), 0 if ws is None else ws.numel(),
+                         stream)
 
     @staticmethod
     def signature(query, key, value, kv_cache):
@@ -443,9 +485,19 @@ class DecodeLayerLauncher:
         kc = kv_cache.data_ptr()
         vc = kc + self.v_off
         lib = self._lib
+        sink = DecodeLayerLauncher.event_sink
+        if self.fused:
+            if sink is not None:
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+            _lib.check(lib.pe_decode_step(out.data_ptr(), query.data_ptr(), key.data_ptr(),
+                                          value.data_ptr(), kc, vc, *self._fs_tail), "decode_step")
+            if sink is not None:
+                e.record()
+                sink.append((s, e))
+            return
         _lib.check(lib.pe_reshape_and_cache(key.data_ptr(), value.data_ptr(), kc, vc, *self._rc_tail),
                    "reshape_and_cache")
-        sink = DecodeLayerLauncher.event_sink
         if sink is None:
             _lib.check(lib.pe_paged_decode(out.data_ptr(), query.data_ptr(), kc, vc, *self._pa_tail),
                        "paged_attention")
