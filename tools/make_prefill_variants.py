@@ -1,0 +1,58 @@
+"""Builds experimental variants of the prefill kernel (wrong results, timing only) into tools/_exp/.
+
+Each variant removes one ingredient of the main loop so that its cost can be read off the
+difference in kernel time:  noload (no global->LDS staging after tile 0), nobar (noload + no
+barrier), nosoftmax (P = S without max/exp), nopv (no P.V MFMAs).
+"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "vllm-paged-compression_amd")
+SRC = os.path.join(PKG, "csrc", "prefill.hip")
+OUT = os.path.join(ROOT, "tools", "_exp")
+
+
+def variant(name, text):
+    if name in ("noload", "nobar"):
+        text = text.replace("if (tile + 1 < n_tiles) stage_load(tile + 1);", "")
+        text = text.replace("if (tile + 1 < n_tiles) stage_store(buf ^ 1);", "")
+        text = text.replace("const int buf = tile & 1;", "const int buf = 0;")
+    if name == "nobar":
+        text = text.replace("      __syncthreads();\n    }\n  };", "    }\n  };")
+    if name == "nosoftmax":
+        text = text.replace(
+            "const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[sub][n][r], scale_log2e, -m_new));",
+            "const float p = s[sub][n][r];")
+    if name == "nopv":
+        text = text.replace("acc[dt][0] = TR::mfma16(vf, pf[0][k2], acc[dt][0]);", "acc[dt][0][0] += vf[0] + pf[0][k2][0];")
+        text = text.replace("acc[dt][1] = TR::mfma16(vf, pf[1][k2], acc[dt][1]);", "acc[dt][1][0] += vf[1] + pf[1][k2][1];")
+    return text
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    base = open(SRC).read()
+    objs = [os.path.join(PKG, "build", f) for f in os.listdir(os.path.join(PKG, "build"))
+            if f.endswith(".o") and f != "prefill.o"]
+    for name in sys.argv[1:] or ["noload", "nobar", "nosoftmax", "nopv"]:
+        text = variant(name, base)
+        assert text != base, name
+        src = os.path.join(PKG, "csrc", f"_exp_{name}.hip")
+        with open(src, "w") as f:
+            f.write(text)
+        try:
+            lib = os.path.join(OUT, f"libpe_{name}.so")
+            obj = os.path.join(OUT, f"prefill_{name}.o")
+            subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+                                   "-I" + os.path.join(ROOT, "include"), "-c", src, "-o", obj])
+            subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, obj, *objs])
+            os.remove(obj)
+            print("built", lib)
+        finally:
+            os.remove(src)
+
+
+if __name__ == "__main__":
+    main()

@@ -18,7 +18,11 @@ def main():
     ap.add_argument("--hkv", type=int, default=8)
     ap.add_argument("--d", type=int, default=128)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--lib", default=None, help="alternative build of the library (timing experiments)")
     a = ap.parse_args()
+    if a.lib:
+        import vllm_paged_compression_amd._lib as _lib
+        _lib.LIB_PATH = os.path.abspath(a.lib)
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     q = torch.randn(a.batch * a.lq, a.hq, a.d, dtype=torch.bfloat16, device=dev)

@@ -16,6 +16,8 @@
 // The finished O tile goes through LDS so that global stores are whole 16-byte row chunks.
 #include "pe_common.h"
 
+#include <type_traits>
+
 namespace pe {
 
 constexpr int PF_WAVES = 4;
@@ -28,9 +30,20 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 template <int D>
 __device__ __forceinline__ int swz_off(int row, int chunk) {
-  // byte offset of 16-byte chunk `chunk` of row `row` in a [rows][D] 16-bit tile
+  // byte offset of 16-byte chunk `chunk` of row `row` in the [rows][D] 16-bit K tile: the 16 rows
+  // a ds_read_b128 lane group touches land on 16 different 16-byte slots of the 256-byte bank row
   constexpr int CPR = D / 8;
   const int x = (CPR == 16) ? (row & 15) : ((row >> 1) & 7);
+  return row * (D * 2) + ((chunk ^ x) << 4);
+}
+
+template <int D>
+__device__ __forceinline__ int swz_off_v(int row, int chunk) {
+  // V tile: a 32-lane half of ds_read_b64_tr_b16 takes 8 consecutive rows x 32 bytes (one chunk
+  // pair per row); XOR-ing the pair index with the row puts the 8 rows on 8 different 32-byte
+  // spans of the bank row
+  constexpr int CPR = D / 8;
+  const int x = (CPR == 16) ? ((row & 7) << 1) : (((row >> 1) & 3) << 1);
   return row * (D * 2) + ((chunk ^ x) << 4);
 }
 
@@ -53,12 +66,16 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_mfma_kernel(
   auto k_tile = [&](int buf) { return smem + buf * 2 * TILE_BYTES; };
   auto v_tile = [&](int buf) { return smem + buf * 2 * TILE_BYTES + TILE_BYTES; };
 
-  const int seq = blockIdx.z;
-  const int head = blockIdx.y;
-  const int kvh = head / (num_heads / num_kv_heads);
+  // grid (head, request, query tile): workgroups are dispatched x-fastest, so every request's
+  // heaviest (last) query tiles start first and the short ones fill the tail; consecutive
+  // workgroup ids go to consecutive XCDs, so x enumerates kv heads fastest - the query heads of
+  // one kv head (which read the same K/V) share an XCD's L2 when num_kv_heads % 8 == 0
+  const int seq = blockIdx.y;
+  const int kvh = (int)blockIdx.x % num_kv_heads;
+  const int head = kvh * (num_heads / num_kv_heads) + (int)blockIdx.x / num_kv_heads;
   const int q0 = cu_q[seq], lq = cu_q[seq + 1] - q0;
   const int kv0 = cu_kv[seq], lkv = cu_kv[seq + 1] - kv0;
-  const int qt = (int)gridDim.x - 1 - (int)blockIdx.x;  // heaviest (last) query tiles first
+  const int qt = (int)gridDim.z - 1 - (int)blockIdx.z;
   const int m0 = qt * PF_BM;
   if (m0 >= lq) return;
 
@@ -90,30 +107,56 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_mfma_kernel(
   const int kv_end = min(lkv, m0 + PF_BM);  // rows past the last query row are never attended
   const int n_tiles = (kv_end + PF_BN - 1) / PF_BN;
 
+  // Staging: thread t moves chunk (t % CPR) of rows t / CPR + i * RSTEP of the tile.  The loads
+  // use the scalar-base + 32-bit-lane-offset form of global_load, so a full tile costs no vector
+  // address arithmetic (the lane offset never changes; tile and i go into the scalar base); only
+  // the ragged last tile of a request clamps its rows per lane.  They are issued from inline asm,
+  // which the compiler's wait-count bookkeeping does not see: stage_wait() must run between a
+  // stage_load and the stage_store that consumes it.
+  constexpr int RSTEP = PF_THREADS / CPR;
+  const int srow = tid / CPR, sch = tid % CPR;
+  const char* k_seq = reinterpret_cast<const char*>(k + (int64_t)kv0 * k_stride + (int64_t)kvh * D);
+  const char* v_seq = reinterpret_cast<const char*>(v + (int64_t)kv0 * v_stride + (int64_t)kvh * D);
+  const uint32_t k_row_bytes = (uint32_t)k_stride * 2u, v_row_bytes = (uint32_t)v_stride * 2u;
+  const uint32_t k_lane_off = (uint32_t)srow * k_row_bytes + (uint32_t)sch * 16u;
+  const uint32_t v_lane_off = (uint32_t)srow * v_row_bytes + (uint32_t)sch * 16u;
   u32x4 stage_k[CHUNKS_PER_THREAD], stage_v[CHUNKS_PER_THREAD];
+  auto load16 = [](u32x4& dst, const char* base, uint32_t lane_off) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(lane_off), "s"(base));
+  };
   auto stage_load = [&](int tile) {
+    const int t0 = tile * PF_BN;
+    const char* kb = k_seq + (int64_t)t0 * k_row_bytes;
+    const char* vb = v_seq + (int64_t)t0 * v_row_bytes;
+    if (t0 + PF_BN <= lkv) {
 #pragma unroll
-    for (int i = 0; i < CHUNKS_PER_THREAD; ++i) {
-      const int idx = tid + i * PF_THREADS;
-      const int row = idx / CPR, ch = idx % CPR;
-      const int kvrow = min(tile * PF_BN + row, lkv - 1);
-      stage_k[i] = *reinterpret_cast<const u32x4*>(k + (int64_t)(kv0 + kvrow) * k_stride +
-                                                   (int64_t)kvh * D + ch * 8);
-      stage_v[i] = *reinterpret_cast<const u32x4*>(v + (int64_t)(kv0 + kvrow) * v_stride +
-                                                   (int64_t)kvh * D + ch * 8);
+      for (int i = 0; i < CHUNKS_PER_THREAD; ++i) {
+        load16(stage_k[i], kb + (int64_t)(i * RSTEP) * k_row_bytes, k_lane_off);
+        load16(stage_v[i], vb + (int64_t)(i * RSTEP) * v_row_bytes, v_lane_off);
+      }
+    } else {
+      const int last = lkv - 1 - t0;  // >= 0: a staged tile starts inside the request
+#pragma unroll
+      for (int i = 0; i < CHUNKS_PER_THREAD; ++i) {
+        const uint32_t row = (uint32_t)min(srow + i * RSTEP, last);
+        load16(stage_k[i], kb, row * k_row_bytes + (uint32_t)sch * 16u);
+        load16(stage_v[i], vb, row * v_row_bytes + (uint32_t)sch * 16u);
+      }
     }
   };
+  auto stage_wait = [] { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
   auto stage_store = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < CHUNKS_PER_THREAD; ++i) {
       const int idx = tid + i * PF_THREADS;
       const int row = idx / CPR, ch = idx % CPR;
       *reinterpret_cast<u32x4*>(k_tile(buf) + swz_off<D>(row, ch)) = stage_k[i];
-      *reinterpret_cast<u32x4*>(v_tile(buf) + swz_off<D>(row, ch)) = stage_v[i];
+      *reinterpret_cast<u32x4*>(v_tile(buf) + swz_off_v<D>(row, ch)) = stage_v[i];
     }
   };
 
-  auto compute = [&](int tile, int buf) {
+  auto compute = [&](int tile, int buf, auto masked_tag) {
+    constexpr bool MASKED = decltype(masked_tag)::value;
     const int n0 = tile * PF_BN;
     const char* kt = k_tile(buf);
     const char* vt = v_tile(buf);
@@ -131,45 +174,46 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_mfma_kernel(
         s[sub][1] = TR::mfma16(kf, qf[1][ks], s[sub][1]);
       }
     }
-    // ---- scale, mask, online softmax ---------------------------------------------------
-    const bool need_mask = (n0 + PF_BN - 1 > wrow0) || (n0 + PF_BN > lkv);  // wave-uniform
+    // ---- mask, online softmax (the scale rides in the exponent's fma; maxima are kept in
+    //      scaled log2 units, which needs scale > 0 - the launcher guarantees it) ----------
     vec8 pf[2][2];
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
-      const int qrow = wrow0 + n * 16 + c;
-      const int limit = min(qrow, lkv - 1);  // last kv row this query row may attend
       float mx = PF_NEG;
+      if constexpr (MASKED) {
+        const int qrow = wrow0 + n * 16 + c;
+        const int limit = min(qrow, lkv - 1) - n0 - 4 * g;  // last attended (sub*16 + r)
 #pragma unroll
-      for (int sub = 0; sub < 4; ++sub) {
+        for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float x = s[sub][n][r] * scale_log2e;
-          if (need_mask) {
-            const int t = n0 + sub * 16 + 4 * g + r;
-            x = t <= limit ? x : PF_NEG;
-          }
-          s[sub][n][r] = x;
-          mx = fmaxf(mx, x);
-        }
+          for (int r = 0; r < 4; ++r)
+            s[sub][n][r] = (sub * 16 + r <= limit) ? s[sub][n][r] : PF_NEG;
       }
+#pragma unroll
+      for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[sub][n][r]);
       mx = fmaxf(mx, __shfl_xor(mx, 16));
       mx = fmaxf(mx, __shfl_xor(mx, 32));
-      const float m_new = fmaxf(m_run[n], mx);
-      const float alpha = __builtin_amdgcn_exp2f(m_run[n] - m_new);
-      m_run[n] = m_new;
+      const float m_new = fmaxf(m_run[n], mx * scale_log2e);
+      if (__builtin_amdgcn_ballot_w64(m_new > m_run[n]) != 0) {  // wave-uniform: some row's max grew
+        const float alpha = __builtin_amdgcn_exp2f(m_run[n] - m_new);
+        m_run[n] = m_new;
+        l_run[n] *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) acc[dt][n] *= alpha;
+      }
       float psum = 0.f;
 #pragma unroll
       for (int sub = 0; sub < 4; ++sub) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float p = __builtin_amdgcn_exp2f(s[sub][n][r] - m_new);
+          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[sub][n][r], scale_log2e, -m_new));
           psum += p;
           pf[n][sub >> 1][(sub & 1) * 4 + r] = (T)p;
         }
       }
-      l_run[n] = l_run[n] * alpha + psum;
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) acc[dt][n] *= alpha;
+      l_run[n] += psum;
     }
     // ---- O^T += V^T.P^T ------------------------------------------------------------------
     // transposed read: lane i of each 16-lane group addresses row (4g + i/4), columns
@@ -184,9 +228,9 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_mfma_kernel(
         const int ch = 2 * dt + (tp >> 1);
         const int sub8 = (tp & 1) * 8;
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) s16x4*)(vt + swz_off<D>(row_lo, ch) + sub8));
+            (__attribute__((address_space(3))) s16x4*)(vt + swz_off_v<D>(row_lo, ch) + sub8));
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) s16x4*)(vt + swz_off<D>(row_hi, ch) + sub8));
+            (__attribute__((address_space(3))) s16x4*)(vt + swz_off_v<D>(row_hi, ch) + sub8));
         typedef __attribute__((ext_vector_type(8))) short s16x8;
         const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         const vec8 vf = __builtin_bit_cast(vec8, both);
@@ -196,18 +240,37 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_mfma_kernel(
     }
   };
 
-  // ---- main loop ----------------------------------------------------------------------------
-  if (n_tiles > 0) {
-    stage_load(0);
-    stage_store(0);
-    __syncthreads();
-    for (int tile = 0; tile < n_tiles; ++tile) {
+  // ---- main loop: tiles every wave attends in full first (no mask code), then the diagonal /
+  //      ragged tiles -------------------------------------------------------------------------
+  auto run_tiles = [&](int t_begin, int t_end, auto masked_tag) {
+    constexpr bool MASKED = decltype(masked_tag)::value;
+    for (int tile = t_begin; tile < t_end; ++tile) {
       const int buf = tile & 1;
       if (tile + 1 < n_tiles) stage_load(tile + 1);
-      if (tile * PF_BN <= wrow0 + 31) compute(tile, buf);  // wave-uniform: tile not fully masked
-      if (tile + 1 < n_tiles) stage_store(buf ^ 1);
+      // wave-uniform: skip a tile that is fully masked for this wave's 32 rows
+      if (!MASKED || tile * PF_BN <= wrow0 + 31) compute(tile, buf, masked_tag);
+      if (tile + 1 < n_tiles) {
+        stage_wait();
+        stage_store(buf ^ 1);
+      }
       __syncthreads();
     }
+  };
+  if (n_tiles > 0) {
+    const int n_full = min(min(m0, lkv) / PF_BN, n_tiles);
+    stage_load(0);
+    stage_wait();
+    stage_store(0);
+    // Retire the Q loads here: an empty asm that "rewrites" the fragments makes the compiler wait
+    // for them before the loop.  Left pending, they make its wait-count bookkeeping drain the
+    // prefetch of the next tile (vmcnt(0)) at the first MFMA of every iteration.
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[n][ks]));
+    __syncthreads();
+    run_tiles(0, n_full, std::false_type{});
+    run_tiles(n_full, n_tiles, std::true_type{});
   }
 
   // ---- epilogue: normalise, stage the wave's 32 x D tile in LDS, store whole rows -----------
@@ -303,12 +366,14 @@ extern "C" int pe_prefill_causal(void* out, const void* q, const void* k, const 
   PE_REQUIRE(num_seqs <= 65535 && num_heads <= 65535, PE_ERR_UNSUPPORTED, "prefill: grid too large");
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool mfma = (dtype == PE_BF16 || dtype == PE_F16) && (head_size == 64 || head_size == 128) &&
+                    scale > 0.f && (max_q_len + PF_BM - 1) / PF_BM <= 65535 &&
+                    k_stride > 0 && v_stride > 0 && k_stride < (1 << 24) && v_stride < (1 << 24) &&
                     q_stride % 8 == 0 && k_stride % 8 == 0 && v_stride % 8 == 0 &&
                     out_stride % 8 == 0 &&
                     (((uintptr_t)out | (uintptr_t)q | (uintptr_t)k | (uintptr_t)v) % 16 == 0);
   if (mfma) {
     const int q_tiles = (max_q_len + PF_BM - 1) / PF_BM;
-    dim3 grid((unsigned)q_tiles, (unsigned)num_heads, (unsigned)num_seqs);
+    dim3 grid((unsigned)num_heads, (unsigned)num_seqs, (unsigned)q_tiles);
     const float sl2 = scale * 1.4426950408889634f;
 #define PE_LAUNCH_PF(T, HS)                                                                        \
   do {                                                                                             \
