@@ -17,8 +17,16 @@ OUT = os.path.join(ROOT, "tools", "_exp")
 def variant(name, text):
     if name in ("noload", "nobar"):
         text = text.replace("if (tile + 1 < n_tiles) stage_load(tile + 1);", "")
-        text = text.replace("if (tile + 1 < n_tiles) stage_store(buf ^ 1);", "")
+        text = text.replace("        stage_wait();\n        stage_store(buf ^ 1);\n", "")
         text = text.replace("const int buf = tile & 1;", "const int buf = 0;")
+    if name == "nowrite":
+        text = text.replace("        stage_store(buf ^ 1);\n", """        for (int i = 0; i < CHUNKS_PER_THREAD; ++i) {
+          asm volatile("" ::"v"(stage_k[i]));
+          asm volatile("" ::"v"(stage_v[i]));
+        }
+""")
+    if name == "nowait":
+        text = text.replace("        stage_wait();\n        stage_store(buf ^ 1);\n", "")
     if name == "nobar":
         text = text.replace("      __syncthreads();\n    }\n  };", "    }\n  };")
     if name == "nosoftmax":

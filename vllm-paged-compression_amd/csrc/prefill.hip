@@ -6,8 +6,8 @@
 // Grouped KV heads are addressed directly (no repeat_interleave copy).
 //
 // MFMA path (16-bit types, head_size 64/128): a workgroup of 4 waves owns 128 query rows of
-// one (request, head); K/V tiles of 64 tokens are staged global -> registers -> LDS
-// (double-buffered, loads of tile j+1 issued before the math of tile j, written after it).
+// one (request, head); K/V tiles of 64 tokens stream global -> LDS directly (LDS-DMA loads,
+// double-buffered: tile j+1 is in flight during the math of tile j).
 //   S^T = K.Q^T   v_mfma_f32_16x16x32: A = K rows from LDS (ds_read_b128, XOR-swizzled
 //                 chunks), B = Q fragments held in registers; a lane ends up with 4 tokens
 //                 x 1 query row, so the row max/sum is a register reduction + 2 shuffles.
@@ -59,7 +59,6 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_mfma_kernel(
   constexpr int DT = D / 16;
   constexpr int CPR = D / 8;                        // 16-byte chunks per row
   constexpr int TILE_BYTES = PF_BN * D * 2;         // one K or V tile
-  constexpr int CHUNKS_PER_THREAD = PF_BN * CPR / PF_THREADS;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // [buf][K|V][tile]
@@ -107,53 +106,65 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_mfma_kernel(
   const int kv_end = min(lkv, m0 + PF_BM);  // rows past the last query row are never attended
   const int n_tiles = (kv_end + PF_BN - 1) / PF_BN;
 
-  // Staging: thread t moves chunk (t % CPR) of rows t / CPR + i * RSTEP of the tile.  The loads
-  // use the scalar-base + 32-bit-lane-offset form of global_load, so a full tile costs no vector
-  // address arithmetic (the lane offset never changes; tile and i go into the scalar base); only
-  // the ragged last tile of a request clamps its rows per lane.  They are issued from inline asm,
-  // which the compiler's wait-count bookkeeping does not see: stage_wait() must run between a
-  // stage_load and the stage_store that consumes it.
-  constexpr int RSTEP = PF_THREADS / CPR;
-  const int srow = tid / CPR, sch = tid % CPR;
+  // Staging: K/V tiles go global -> LDS directly (global_load_lds_dwordx4, no registers, no
+  // ds_write).  One wave-instruction fills 1 KiB of LDS contiguously in lane order: RPI whole tile
+  // rows, lane l -> row l / CPR, 16-byte slot l % CPR.  The XOR swizzle of the LDS image is applied
+  // to the per-lane SOURCE chunk instead (slot s of a row holds chunk s ^ x(row)).  Wave w issues
+  // instruction i for rows i * RSTEP + w * RPI ..., so x(row) does not depend on i and the
+  // per-lane source offset is one constant; tile and i go into the scalar base.  Only the ragged
+  // last tile of a request clamps its rows per lane.  The loads are asm statements the compiler
+  // does not count: stage_wait() + a barrier must separate them from the reads of the tile.
+  constexpr int RPI = 64 / CPR;            // tile rows per wave-instruction
+  constexpr int RSTEP = PF_WAVES * RPI;    // rows between a wave's consecutive instructions
+  constexpr int NINST = PF_BN / RSTEP;     // instructions per wave per operand tile
+  const int lrow = wave * RPI + lane / CPR;  // row within a RSTEP group
+  const int lslot = lane % CPR;
   const char* k_seq = reinterpret_cast<const char*>(k + (int64_t)kv0 * k_stride + (int64_t)kvh * D);
   const char* v_seq = reinterpret_cast<const char*>(v + (int64_t)kv0 * v_stride + (int64_t)kvh * D);
   const uint32_t k_row_bytes = (uint32_t)k_stride * 2u, v_row_bytes = (uint32_t)v_stride * 2u;
-  const uint32_t k_lane_off = (uint32_t)srow * k_row_bytes + (uint32_t)sch * 16u;
-  const uint32_t v_lane_off = (uint32_t)srow * v_row_bytes + (uint32_t)sch * 16u;
-  u32x4 stage_k[CHUNKS_PER_THREAD], stage_v[CHUNKS_PER_THREAD];
-  auto load16 = [](u32x4& dst, const char* base, uint32_t lane_off) {
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(lane_off), "s"(base));
+  // source chunk for this lane's slot: the inverse of swz_off / swz_off_v (XOR is an involution)
+  const uint32_t k_chunk16 = (uint32_t)(swz_off<D>(lrow, lslot) - lrow * (D * 2));
+  const uint32_t v_chunk16 = (uint32_t)(swz_off_v<D>(lrow, lslot) - lrow * (D * 2));
+  const uint32_t k_lane_off = (uint32_t)lrow * k_row_bytes + k_chunk16;
+  const uint32_t v_lane_off = (uint32_t)lrow * v_row_bytes + v_chunk16;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem +
+                        (uint32_t)wave * 1024u;
+  auto glds16 = [](const char* base, uint32_t lane_off, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_nop 4\n\t"
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(lane_off), "s"(base), "s"(lds_dst)
+        : "memory");
   };
-  auto stage_load = [&](int tile) {
+  auto stage = [&](int tile, int buf) {
     const int t0 = tile * PF_BN;
     const char* kb = k_seq + (int64_t)t0 * k_row_bytes;
     const char* vb = v_seq + (int64_t)t0 * v_row_bytes;
+    const uint32_t kd = lds0 + (uint32_t)buf * (2u * TILE_BYTES);
+    const uint32_t vd = kd + TILE_BYTES;
     if (t0 + PF_BN <= lkv) {
 #pragma unroll
-      for (int i = 0; i < CHUNKS_PER_THREAD; ++i) {
-        load16(stage_k[i], kb + (int64_t)(i * RSTEP) * k_row_bytes, k_lane_off);
-        load16(stage_v[i], vb + (int64_t)(i * RSTEP) * v_row_bytes, v_lane_off);
+      for (int i = 0; i < NINST; ++i) {
+        glds16(kb + (int64_t)(i * RSTEP) * k_row_bytes, k_lane_off, kd + i * RSTEP * D * 2);
+        glds16(vb + (int64_t)(i * RSTEP) * v_row_bytes, v_lane_off, vd + i * RSTEP * D * 2);
       }
     } else {
       const int last = lkv - 1 - t0;  // >= 0: a staged tile starts inside the request
 #pragma unroll
-      for (int i = 0; i < CHUNKS_PER_THREAD; ++i) {
-        const uint32_t row = (uint32_t)min(srow + i * RSTEP, last);
-        load16(stage_k[i], kb, row * k_row_bytes + (uint32_t)sch * 16u);
-        load16(stage_v[i], vb, row * v_row_bytes + (uint32_t)sch * 16u);
+      for (int i = 0; i < NINST; ++i) {
+        const uint32_t row = (uint32_t)min(lrow + i * RSTEP, last);
+        glds16(kb, row * k_row_bytes + k_chunk16, kd + i * RSTEP * D * 2);
+        glds16(vb, row * v_row_bytes + v_chunk16, vd + i * RSTEP * D * 2);
       }
     }
   };
   auto stage_wait = [] { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
-  auto stage_store = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < CHUNKS_PER_THREAD; ++i) {
-      const int idx = tid + i * PF_THREADS;
-      const int row = idx / CPR, ch = idx % CPR;
-      *reinterpret_cast<u32x4*>(k_tile(buf) + swz_off<D>(row, ch)) = stage_k[i];
-      *reinterpret_cast<u32x4*>(v_tile(buf) + swz_off_v<D>(row, ch)) = stage_v[i];
-    }
-  };
 
   auto compute = [&](int tile, int buf, auto masked_tag) {
     constexpr bool MASKED = decltype(masked_tag)::value;
@@ -241,33 +252,29 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_mfma_kernel(
   };
 
   // ---- main loop: tiles every wave attends in full first (no mask code), then the diagonal /
-  //      ragged tiles -------------------------------------------------------------------------
+  //      ragged tiles.  Tile t+1 streams into the other LDS buffer while tile t is computed. -----
   auto run_tiles = [&](int t_begin, int t_end, auto masked_tag) {
     constexpr bool MASKED = decltype(masked_tag)::value;
     for (int tile = t_begin; tile < t_end; ++tile) {
       const int buf = tile & 1;
-      if (tile + 1 < n_tiles) stage_load(tile + 1);
+      if (tile + 1 < n_tiles) stage(tile + 1, buf ^ 1);
       // wave-uniform: skip a tile that is fully masked for this wave's 32 rows
       if (!MASKED || tile * PF_BN <= wrow0 + 31) compute(tile, buf, masked_tag);
-      if (tile + 1 < n_tiles) {
-        stage_wait();
-        stage_store(buf ^ 1);
-      }
+      stage_wait();
       __syncthreads();
     }
   };
   if (n_tiles > 0) {
     const int n_full = min(min(m0, lkv) / PF_BN, n_tiles);
-    stage_load(0);
-    stage_wait();
-    stage_store(0);
+    stage(0, 0);
     // Retire the Q loads here: an empty asm that "rewrites" the fragments makes the compiler wait
-    // for them before the loop.  Left pending, they make its wait-count bookkeeping drain the
-    // prefetch of the next tile (vmcnt(0)) at the first MFMA of every iteration.
+    // for them before the loop instead of carrying them as pending into its wait-count
+    // bookkeeping of every iteration.
 #pragma unroll
     for (int n = 0; n < 2; ++n)
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[n][ks]));
+    stage_wait();
     __syncthreads();
     run_tiles(0, n_full, std::false_type{});
     run_tiles(n_full, n_tiles, std::true_type{});
