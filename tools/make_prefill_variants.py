@@ -2,7 +2,7 @@
 
 Each variant removes one ingredient of the main loop so that its cost can be read off the
 difference in kernel time:  noload (no global->LDS staging after tile 0), nobar (noload + no
-barrier), nosoftmax (P = S without max/exp), nopv (no P.V MFMAs).
+barrier), nosoftmax (no exp2), novalu (no max / exp2 / rescale), nopv (no P.V MFMAs).
 """
 import os
 import subprocess
@@ -16,23 +16,21 @@ OUT = os.path.join(ROOT, "tools", "_exp")
 
 def variant(name, text):
     if name in ("noload", "nobar"):
-        text = text.replace("if (tile + 1 < n_tiles) stage_load(tile + 1);", "")
-        text = text.replace("        stage_wait();\n        stage_store(buf ^ 1);\n", "")
+        text = text.replace("if (tile + 1 < n_tiles) stage(tile + 1, buf ^ 1);", "")
         text = text.replace("const int buf = tile & 1;", "const int buf = 0;")
-    if name == "nowrite":
-        text = text.replace("        stage_store(buf ^ 1);\n", """        for (int i = 0; i < CHUNKS_PER_THREAD; ++i) {
-          asm volatile("" ::"v"(stage_k[i]));
-          asm volatile("" ::"v"(stage_v[i]));
-        }
-""")
-    if name == "nowait":
-        text = text.replace("        stage_wait();\n        stage_store(buf ^ 1);\n", "")
     if name == "nobar":
-        text = text.replace("      __syncthreads();\n    }\n  };", "    }\n  };")
+        text = text.replace("      stage_wait();\n      __syncthreads();\n    }\n  };", "    }\n  };")
     if name == "nosoftmax":
         text = text.replace(
             "const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[sub][n][r], scale_log2e, -m_new));",
             "const float p = s[sub][n][r];")
+    if name == "novalu":
+        # no max, no exp, no rescale: P is the raw S (wrong numbers, same MFMA / LDS work)
+        text = text.replace("for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[sub][n][r]);", "for (int r = 0; r < 1; ++r) mx = fmaxf(mx, s[sub][n][r]);")
+        text = text.replace(
+            "const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[sub][n][r], scale_log2e, -m_new));",
+            "const float p = s[sub][n][r];")
+        text = text.replace("if (__builtin_amdgcn_ballot_w64(m_new > m_run[n]) != 0) {", "if (m_new > 1e30f) {")
     if name == "nopv":
         text = text.replace("acc[dt][0] = TR::mfma16(vf, pf[0][k2], acc[dt][0]);", "acc[dt][0][0] += vf[0] + pf[0][k2][0];")
         text = text.replace("acc[dt][1] = TR::mfma16(vf, pf[1][k2], acc[dt][1]);", "acc[dt][1][0] += vf[1] + pf[1][k2][1];")
@@ -44,7 +42,7 @@ def main():
     base = open(SRC).read()
     objs = [os.path.join(PKG, "build", f) for f in os.listdir(os.path.join(PKG, "build"))
             if f.endswith(".o") and f != "prefill.o"]
-    for name in sys.argv[1:] or ["noload", "nobar", "nosoftmax", "nopv"]:
+    for name in sys.argv[1:] or ["noload", "nobar", "nosoftmax", "novalu", "nopv"]:
         text = variant(name, base)
         assert text != base, name
         src = os.path.join(PKG, "csrc", f"_exp_{name}.hip")

@@ -16,14 +16,13 @@
 // The finished O tile goes through LDS so that global stores are whole 16-byte row chunks.
 #include "pe_common.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace pe {
 
-constexpr int PF_WAVES = 4;
-constexpr int PF_THREADS = PF_WAVES * 64;
-constexpr int PF_BM = 128;  // query rows per workgroup (32 per wave)
 constexpr int PF_BN = 64;   // kv rows per tile
+constexpr int PF_DEFAULT_SHAPE = 24;
 constexpr float PF_NEG = -1.0e30f;
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -47,8 +46,10 @@ __device__ __forceinline__ int swz_off_v(int row, int chunk) {
   return row * (D * 2) + ((chunk ^ x) << 4);
 }
 
-template <typename T, int D>
-__global__ __launch_bounds__(PF_THREADS, 2) void prefill_mfma_kernel(
+// NR: 16-row query tiles per wave; WAVES: waves per workgroup (query rows per workgroup =
+// 16 * NR * WAVES); WPE: waves per SIMD the register budget is cut for.
+template <typename T, int D, int NR, int WAVES, int WPE>
+__global__ __launch_bounds__(WAVES * 64, WPE) void prefill_mfma_kernel(
     T* __restrict__ out, const T* __restrict__ q, const T* __restrict__ k,
     const T* __restrict__ v, const int32_t* __restrict__ cu_q, const int32_t* __restrict__ cu_kv,
     int num_heads, int num_kv_heads, int64_t q_stride, int64_t k_stride, int64_t v_stride,
@@ -59,6 +60,9 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_mfma_kernel(
   constexpr int DT = D / 16;
   constexpr int CPR = D / 8;                        // 16-byte chunks per row
   constexpr int TILE_BYTES = PF_BN * D * 2;         // one K or V tile
+  constexpr int WROWS = 16 * NR;                    // query rows per wave
+  constexpr int BM = WROWS * WAVES;                 // query rows per workgroup
+  static_assert(BM % PF_BN == 0 && BM * D * 2 <= 4 * TILE_BYTES, "tile shape");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // [buf][K|V][tile]
@@ -75,19 +79,19 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_mfma_kernel(
   const int q0 = cu_q[seq], lq = cu_q[seq + 1] - q0;
   const int kv0 = cu_kv[seq], lkv = cu_kv[seq + 1] - kv0;
   const int qt = (int)gridDim.z - 1 - (int)blockIdx.z;
-  const int m0 = qt * PF_BM;
+  const int m0 = qt * BM;
   if (m0 >= lq) return;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, c = lane & 15;
-  const int wrow0 = m0 + wave * 32;  // first query row of this wave
+  const int wrow0 = m0 + wave * WROWS;  // first query row of this wave
 
-  // ---- Q fragments (B operand): lane holds Q[row][32ks + 8g .. +8) for its 2 row tiles ----
-  vec8 qf[2][KS];
+  // ---- Q fragments (B operand): lane holds Q[row][32ks + 8g .. +8) for its row tiles ----
+  vec8 qf[NR][KS];
 #pragma unroll
-  for (int n = 0; n < 2; ++n) {
+  for (int n = 0; n < NR; ++n) {
     const int row = min(wrow0 + n * 16 + c, lq - 1);
     const T* qp = q + (int64_t)(q0 + row) * q_stride + (int64_t)head * D + 8 * g;
 #pragma unroll
@@ -95,28 +99,32 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_mfma_kernel(
       qf[n][ks] = __builtin_bit_cast(vec8, *reinterpret_cast<const u32x4*>(qp + 32 * ks));
   }
 
-  float m_run[2] = {PF_NEG, PF_NEG};
-  float l_run[2] = {0.f, 0.f};
-  f32x4 acc[DT][2];
+  float m_run[NR], l_run[NR];
+  f32x4 acc[DT][NR];
 #pragma unroll
-  for (int dt = 0; dt < DT; ++dt)
+  for (int n = 0; n < NR; ++n) {
+    m_run[n] = PF_NEG;
+    l_run[n] = 0.f;
 #pragma unroll
-    for (int n = 0; n < 2; ++n) acc[dt][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int dt = 0; dt < DT; ++dt) acc[dt][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
-  const int kv_end = min(lkv, m0 + PF_BM);  // rows past the last query row are never attended
+  const int kv_end = min(lkv, m0 + BM);  // rows past the last query row are never attended
   const int n_tiles = (kv_end + PF_BN - 1) / PF_BN;
 
   // Staging: K/V tiles go global -> LDS directly (global_load_lds_dwordx4, no registers, no
   // ds_write).  One wave-instruction fills 1 KiB of LDS contiguously in lane order: RPI whole tile
   // rows, lane l -> row l / CPR, 16-byte slot l % CPR.  The XOR swizzle of the LDS image is applied
   // to the per-lane SOURCE chunk instead (slot s of a row holds chunk s ^ x(row)).  Wave w issues
-  // instruction i for rows i * RSTEP + w * RPI ..., so x(row) does not depend on i and the
-  // per-lane source offset is one constant; tile and i go into the scalar base.  Only the ragged
-  // last tile of a request clamps its rows per lane.  The loads are asm statements the compiler
-  // does not count: stage_wait() + a barrier must separate them from the reads of the tile.
+  // instruction i for rows i * RSTEP + w * RPI ..., so x(row) does not depend on i (RSTEP is a
+  // multiple of 16) and the per-lane source offset is one constant; tile and i go into the scalar
+  // base.  Only the ragged last tile of a request clamps its rows per lane.  The loads are asm
+  // statements the compiler does not count: stage_wait() + a barrier must separate them from the
+  // reads of the tile.
   constexpr int RPI = 64 / CPR;            // tile rows per wave-instruction
-  constexpr int RSTEP = PF_WAVES * RPI;    // rows between a wave's consecutive instructions
+  constexpr int RSTEP = WAVES * RPI;       // rows between a wave's consecutive instructions
   constexpr int NINST = PF_BN / RSTEP;     // instructions per wave per operand tile
+  static_assert(RSTEP % 16 == 0 && NINST >= 1 && NINST * RSTEP == PF_BN, "staging shape");
   const int lrow = wave * RPI + lane / CPR;  // row within a RSTEP group
   const int lslot = lane % CPR;
   const char* k_seq = reinterpret_cast<const char*>(k + (int64_t)kv0 * k_stride + (int64_t)kvh * D);
@@ -172,24 +180,24 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_mfma_kernel(
     const char* kt = k_tile(buf);
     const char* vt = v_tile(buf);
     // ---- S^T = K.Q^T ---------------------------------------------------------------
-    f32x4 s[4][2];
+    f32x4 s[4][NR];
 #pragma unroll
     for (int sub = 0; sub < 4; ++sub) {
-      s[sub][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-      s[sub][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int n = 0; n < NR; ++n) s[sub][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const vec8 kf = __builtin_bit_cast(
             vec8, *reinterpret_cast<const u32x4*>(kt + swz_off<D>(sub * 16 + c, 4 * ks + g)));
-        s[sub][0] = TR::mfma16(kf, qf[0][ks], s[sub][0]);
-        s[sub][1] = TR::mfma16(kf, qf[1][ks], s[sub][1]);
+#pragma unroll
+        for (int n = 0; n < NR; ++n) s[sub][n] = TR::mfma16(kf, qf[n][ks], s[sub][n]);
       }
     }
     // ---- mask, online softmax (the scale rides in the exponent's fma; maxima are kept in
     //      scaled log2 units, which needs scale > 0 - the launcher guarantees it) ----------
-    vec8 pf[2][2];
+    vec8 pf[NR][2];
 #pragma unroll
-    for (int n = 0; n < 2; ++n) {
+    for (int n = 0; n < NR; ++n) {
       float mx = PF_NEG;
       if constexpr (MASKED) {
         const int qrow = wrow0 + n * 16 + c;
@@ -245,8 +253,8 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_mfma_kernel(
         typedef __attribute__((ext_vector_type(8))) short s16x8;
         const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         const vec8 vf = __builtin_bit_cast(vec8, both);
-        acc[dt][0] = TR::mfma16(vf, pf[0][k2], acc[dt][0]);
-        acc[dt][1] = TR::mfma16(vf, pf[1][k2], acc[dt][1]);
+#pragma unroll
+        for (int n = 0; n < NR; ++n) acc[dt][n] = TR::mfma16(vf, pf[n][k2], acc[dt][n]);
       }
     }
   };
@@ -258,8 +266,8 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_mfma_kernel(
     for (int tile = t_begin; tile < t_end; ++tile) {
       const int buf = tile & 1;
       if (tile + 1 < n_tiles) stage(tile + 1, buf ^ 1);
-      // wave-uniform: skip a tile that is fully masked for this wave's 32 rows
-      if (!MASKED || tile * PF_BN <= wrow0 + 31) compute(tile, buf, masked_tag);
+      // wave-uniform: skip a tile that is fully masked for all of this wave's rows
+      if (!MASKED || tile * PF_BN <= wrow0 + WROWS - 1) compute(tile, buf, masked_tag);
       stage_wait();
       __syncthreads();
     }
@@ -271,7 +279,7 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_mfma_kernel(
     // for them before the loop instead of carrying them as pending into its wait-count
     // bookkeeping of every iteration.
 #pragma unroll
-    for (int n = 0; n < 2; ++n)
+    for (int n = 0; n < NR; ++n)
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[n][ks]));
     stage_wait();
@@ -280,10 +288,12 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_mfma_kernel(
     run_tiles(n_full, n_tiles, std::true_type{});
   }
 
-  // ---- epilogue: normalise, stage the wave's 32 x D tile in LDS, store whole rows -----------
-  T* o_lds = reinterpret_cast<T*>(smem + wave * (32 * D * 2));
+  // ---- epilogue: normalise, stage the wave's WROWS x D tile in LDS, store whole rows ---------
+  // The 16 lanes of a group write 8 bytes each to 16 different rows: 8-byte unit u of row r goes
+  // to unit u ^ (r & 15) so that they cover the 128-byte bank window once.
+  char* o_lds = smem + wave * (WROWS * D * 2);
 #pragma unroll
-  for (int n = 0; n < 2; ++n) {
+  for (int n = 0; n < NR; ++n) {
     float l = l_run[n];
     l += __shfl_xor(l, 16);
     l += __shfl_xor(l, 32);
@@ -293,18 +303,22 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_mfma_kernel(
       typename TR::vec4 o4;
 #pragma unroll
       for (int r = 0; r < 4; ++r) o4[r] = (T)(acc[dt][n][r] * inv);
-      *reinterpret_cast<typename TR::vec4*>(o_lds + (n * 16 + c) * D + 16 * dt + 4 * g) = o4;
+      *reinterpret_cast<typename TR::vec4*>(o_lds + (n * 16 + c) * (D * 2) + (((4 * dt + g) ^ c) << 3)) = o4;
     }
   }
   __syncthreads();
+  typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 #pragma unroll
-  for (int i = 0; i < 32 * CPR / 64; ++i) {
+  for (int i = 0; i < WROWS * CPR / 64; ++i) {
     const int idx = lane + i * 64;
     const int row = idx / CPR, ch = idx % CPR;
     const int qrow = wrow0 + row;
+    const int x = row & 15;
+    const u32x2 lo = *reinterpret_cast<const u32x2*>(o_lds + row * (D * 2) + (((2 * ch) ^ x) << 3));
+    const u32x2 hi = *reinterpret_cast<const u32x2*>(o_lds + row * (D * 2) + (((2 * ch + 1) ^ x) << 3));
     if (qrow < lq) {
       *reinterpret_cast<u32x4*>(out + (int64_t)(q0 + qrow) * out_stride + (int64_t)head * D + ch * 8) =
-          *reinterpret_cast<const u32x4*>(o_lds + row * D + ch * 8);
+          u32x4{lo[0], lo[1], hi[0], hi[1]};
     }
   }
 }
@@ -373,26 +387,42 @@ extern "C" int pe_prefill_causal(void* out, const void* q, const void* k, const 
   PE_REQUIRE(num_seqs <= 65535 && num_heads <= 65535, PE_ERR_UNSUPPORTED, "prefill: grid too large");
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool mfma = (dtype == PE_BF16 || dtype == PE_F16) && (head_size == 64 || head_size == 128) &&
-                    scale > 0.f && (max_q_len + PF_BM - 1) / PF_BM <= 65535 &&
+                    scale > 0.f && max_q_len / 64 < 65535 &&
                     k_stride > 0 && v_stride > 0 && k_stride < (1 << 24) && v_stride < (1 << 24) &&
                     q_stride % 8 == 0 && k_stride % 8 == 0 && v_stride % 8 == 0 &&
                     out_stride % 8 == 0 &&
                     (((uintptr_t)out | (uintptr_t)q | (uintptr_t)k | (uintptr_t)v) % 16 == 0);
   if (mfma) {
-    const int q_tiles = (max_q_len + PF_BM - 1) / PF_BM;
-    dim3 grid((unsigned)num_heads, (unsigned)num_seqs, (unsigned)q_tiles);
+    // tile shape: PE_PREFILL_SHAPE=<NR><WAVES> picks rows-per-wave / waves-per-workgroup
+    // (24 = 32 rows x 4 waves, 18 = 16 x 8, 28 = 32 x 8, 14 = 16 x 4) for tuning runs
+    static const int shape = [] {
+      const char* e = getenv("PE_PREFILL_SHAPE");
+      return e ? atoi(e) : PF_DEFAULT_SHAPE;
+    }();
     const float sl2 = scale * 1.4426950408889634f;
-#define PE_LAUNCH_PF(T, HS)                                                                        \
+#define PE_LAUNCH_PF(T, HS, NR, WAVES, WPE)                                                        \
   do {                                                                                             \
+    const int bm = 16 * NR * WAVES;                                                                \
+    dim3 grid((unsigned)num_heads, (unsigned)num_seqs, (unsigned)((max_q_len + bm - 1) / bm));     \
     const size_t lds = 4 * (size_t)PF_BN * HS * 2;                                                 \
-    hipLaunchKernelGGL((prefill_mfma_kernel<T, HS>), grid, dim3(PF_THREADS), lds, st, (T*)out,      \
-                       (const T*)q, (const T*)k, (const T*)v, cu_q, cu_kv, num_heads, num_kv_heads, \
-                       q_stride, k_stride, v_stride, out_stride, sl2);                             \
+    hipLaunchKernelGGL((prefill_mfma_kernel<T, HS, NR, WAVES, WPE>), grid, dim3(WAVES * 64), lds,  \
+                       st, (T*)out, (const T*)q, (const T*)k, (const T*)v, cu_q, cu_kv, num_heads, \
+                       num_kv_heads, q_stride, k_stride, v_stride, out_stride, sl2);               \
+  } while (0)
+#define PE_LAUNCH_PF_SHAPE(T, HS)                                                                  \
+  do {                                                                                             \
+    switch (shape) {                                                                               \
+      case 18: PE_LAUNCH_PF(T, HS, 1, 8, 4); break;                                                \
+      case 28: PE_LAUNCH_PF(T, HS, 2, 8, 2); break;                                                \
+      case 14: PE_LAUNCH_PF(T, HS, 1, 4, 4); break;                                                \
+      default: PE_LAUNCH_PF(T, HS, 2, 4, 2); break;                                                \
+    }                                                                                              \
   } while (0)
     PE_DISPATCH_16(dtype, T, {
-      if (head_size == 64) PE_LAUNCH_PF(T, 64);
-      else PE_LAUNCH_PF(T, 128);
+      if (head_size == 64) PE_LAUNCH_PF_SHAPE(T, 64);
+      else PE_LAUNCH_PF_SHAPE(T, 128);
     });
+#undef PE_LAUNCH_PF_SHAPE
 #undef PE_LAUNCH_PF
     return check_launch("prefill_causal");
   }
