@@ -24,9 +24,10 @@ from dataclasses import dataclass, field, fields
 from itertools import accumulate
 from typing import Any, Dict, List, Optional, Tuple, Type
 
+import numpy as np
 import torch
 
-from . import ops, parallel
+from . import ops, parallel, staging
 from .block_l2norm_manager import BlockL2NormManager
 from .config import CompatFlags, PagedEvictConfig
 from .paged_attn import PagedAttention
@@ -296,33 +297,41 @@ class PagedEvictMetadataBuilder(_BuilderBase):
             self._add_seq_group(inter_data,
                                 getattr(self.input_builder, "chunked_prefill_enabled", False))
         device = self.runner.device
+        # block tables as one padded int32 matrix; every array of the step goes up in one
+        # asynchronous copy through pinned memory
         max_blocks = max((len(t) for t in self.block_tables), default=0)
-        bt = torch.zeros((len(self.block_tables), max_blocks), dtype=torch.int32)
-        for i, t in enumerate(self.block_tables):
-            if t:
-                bt[i, :len(t)] = torch.tensor(t, dtype=torch.int32)
-
-        def h2d(data, dtype):
-            return torch.tensor(data, dtype=dtype).to(device, non_blocking=True)
+        pad = [0] * max_blocks
+        bt_np = np.array([t + pad[len(t):] for t in self.block_tables], dtype=np.int32).reshape(
+            len(self.block_tables), max_blocks)
+        i32 = np.int32
+        (slot_mapping_t, seq_lens_t, query_start_t, seq_start_t, context_lens_t, bt,
+         seq_kv_lens_t) = staging.upload([
+             np.asarray(self.slot_mapping, dtype=np.int64),
+             np.asarray(seq_lens, dtype=i32),
+             np.asarray(list(accumulate(query_lens, initial=0)), dtype=i32),
+             np.asarray(list(accumulate(seq_lens, initial=0)), dtype=i32),
+             np.asarray(self.context_lens, dtype=i32),
+             bt_np,
+             np.asarray(self.seq_kv_lens, dtype=i32)], device)
 
         return PagedEvictMetadata(
             num_prefills=self.num_prefills,
-            slot_mapping=h2d(self.slot_mapping, torch.long),
+            slot_mapping=slot_mapping_t,
             multi_modal_placeholder_index_maps=None,
             num_prefill_tokens=self.num_prefill_tokens,
             num_decode_tokens=self.num_decode_tokens,
             seq_lens=seq_lens,
-            seq_lens_tensor=h2d(seq_lens, torch.int),
+            seq_lens_tensor=seq_lens_t,
             max_query_len=max(query_lens),
             max_prefill_seq_len=max(self.prefill_seq_lens, default=0),
             max_decode_seq_len=max(self.curr_seq_lens, default=0),
-            query_start_loc=h2d(list(accumulate(query_lens, initial=0)), torch.int32),
-            seq_start_loc=h2d(list(accumulate(seq_lens, initial=0)), torch.int32),
-            context_lens_tensor=h2d(self.context_lens, torch.int),
-            block_tables=bt.to(device, non_blocking=True),
+            query_start_loc=query_start_t,
+            seq_start_loc=seq_start_t,
+            context_lens_tensor=context_lens_t,
+            block_tables=bt,
             use_cuda_graph=False,
             seq_kv_lens=self.seq_kv_lens,
-            seq_kv_lens_tensor=h2d(self.seq_kv_lens, torch.int),
+            seq_kv_lens_tensor=seq_kv_lens_t,
             reqid_mapping_blocktables=self.reqid_mapping_blocktables)
 
 
@@ -337,16 +346,32 @@ class DeviceScoreTable:
         self.counts = torch.zeros(rows, dtype=torch.int32, device=device)
         self._free = list(range(rows - 1, -1, -1))
         self._row: Dict[Tuple[str, int], int] = {}
+        self._new: List[int] = []
 
     def row_of(self, key: Tuple[str, int]) -> int:
+        """Row of a sequence; a sequence seen for the first time gets a free row whose count is
+        cleared by the next ``flush_new_rows``."""
         r = self._row.get(key)
         if r is None:
             if not self._free:
                 raise RuntimeError("DeviceScoreTable: more live sequences than rows")
             r = self._free.pop()
             self._row[key] = r
-            self.counts[r] = 0
+            self._new.append(r)
         return r
+
+    def flush_new_rows(self) -> None:
+        """Zero the counts of rows handed out since the last flush (one launch for all of them)."""
+        if self._new:
+            idx = staging.upload([np.asarray(self._new, dtype=np.int64)], self.counts.device)[0]
+            self.counts.index_fill_(0, idx, 0)
+            self._new = []
+
+    def set_counts(self, rows: List[int], counts: List[int]) -> None:
+        idx, val = staging.upload([np.asarray(rows, dtype=np.int64),
+                                   np.asarray(counts, dtype=np.int32)], self.counts.device)
+        self.counts.index_copy_(0, idx, val)
+        self._new = [r for r in self._new if r not in set(rows)]
 
     def retain_only(self, live: List[Tuple[str, int]]) -> None:
         live_set = set(live)
@@ -408,6 +433,7 @@ class PagedEvictImpl(_ImplBase):
         random.seed(1234)  # the reference seeds the global RNG in every impl (:796)
         self.reqids_mapping_rmv_blockIdx: Dict[int, Tuple[str, int]] = {}
         self._pending_rmv: Optional[torch.Tensor] = None
+        self._pending_readback: Optional[staging.AsyncReadback] = None
         self._pending_reqs: Optional[List[str]] = None
         self._score_table: Optional[DeviceScoreTable] = None
         self.max_num_seqs = int(kwargs.get("max_num_seqs", 256))
@@ -417,8 +443,11 @@ class PagedEvictImpl(_ImplBase):
     def get_rmv_block_idx(self) -> Dict[int, Tuple[str, int]]:
         """{batch index: (request id, block index to free)} decided in the last forward."""
         if self._pending_rmv is not None:
-            rmv = self._pending_rmv.cpu().tolist()
-            self._pending_rmv = None
+            # the copy was queued right behind the decision kernel: wait for it alone, not for
+            # the attention launches of the step queued after it
+            rb = self._pending_readback
+            rmv = rb.tolist() if rb is not None else self._pending_rmv.cpu().tolist()
+            self._pending_rmv = self._pending_readback = None
             reqs = self._pending_reqs
             self.reqids_mapping_rmv_blockIdx = {i: (reqs[i], r) for i, r in enumerate(rmv) if r >= 0}
         return self.reqids_mapping_rmv_blockIdx
@@ -433,7 +462,7 @@ class PagedEvictImpl(_ImplBase):
         if attn_type != AttentionType.DECODER:
             raise NotImplementedError("Paged eviction is only enabled for decoder attention")
         self.reqids_mapping_rmv_blockIdx = {}
-        self._pending_rmv = None
+        self._pending_rmv = self._pending_readback = None
         T = query.shape[0]
         # decode layers after the first of a step: metadata already validated, decision taken
         launcher = attn_metadata._pe_step.get("launcher")
@@ -441,6 +470,7 @@ class PagedEvictImpl(_ImplBase):
             dec = attn_metadata._pe_step.get("decode")
             if dec is not None:
                 self._pending_rmv, self._pending_reqs = dec["rmv"], dec.get("req_ids")
+                self._pending_readback = dec.get("readback")
                 self.reqids_mapping_rmv_blockIdx = dec["host_rmv"] or {}
             o = torch.empty_like(query) if output is None else output
             launcher.run(query, key, value, kv_cache, o)
@@ -559,14 +589,17 @@ class PagedEvictImpl(_ImplBase):
         table = self._table(values.device)
         self._sync_rows(table)
         off = 0
+        rows, counts = [], []
         for i, n in enumerate(kept):
             nb = n // bs
             row = table.row_of(self.block_l2norm_mgr.get_reqid_and_seqid(i))
             if nb > 0:
                 self.kv_cache_pruner.get_block_scores_dense(values[off:off + nb * bs], nb,
                                                             out=table.scores[row, :nb])
-            table.counts[row] = nb
+            rows.append(row)
+            counts.append(nb)
             off += n
+        table.set_counts(rows, counts)
 
     def _sync_rows(self, table: DeviceScoreTable) -> None:
         table.retain_only(list(self.block_l2norm_mgr.flat_sequence_map))
@@ -586,10 +619,23 @@ class PagedEvictImpl(_ImplBase):
                 block_tables = dec["tables"]
             zero_slots = dec["zero_slots"]
             self._pending_rmv, self._pending_reqs = dec["rmv"], dec.get("req_ids")
+            self._pending_readback = dec.get("readback")
             self.reqids_mapping_rmv_blockIdx = dec["host_rmv"] or {}
-        # every layer of the step launches with the same metadata: validate once, then reuse
+        # every layer of the step launches with the same metadata: validate once (first layer of
+        # the step), then reuse the argument list
         step = meta._pe_step
         launcher = step.get("launcher")
+        if launcher is None and "launcher" not in step and kv_cache is not None and n0 == 0 \
+                and not self.compat.per_layer_decision:
+            try:
+                launcher = ops.DecodeLayerLauncher(q, k, v, kv_cache, self.num_heads, self.num_kv_heads,
+                                                   self.head_size, dm.slot_mapping, zero_slots,
+                                                   block_tables, seq_lens_arg, dm.max_decode_seq_len,
+                                                   self.scale)
+                launcher.tables, launcher.zero = block_tables, zero_slots
+            except RuntimeError:
+                launcher = None  # shape outside the launcher's contract: per-op path below
+            step["launcher"] = launcher
         if (launcher is not None and launcher.tables is block_tables and launcher.zero is zero_slots
                 and kv_cache is not None and launcher.matches(q, k, v, kv_cache)):
             launcher.run(q, k, v, kv_cache, out[n0:])
@@ -599,16 +645,6 @@ class PagedEvictImpl(_ImplBase):
         PagedAttention.forward_decode(q, key_cache, value_cache, block_tables, seq_lens_arg,
                                       dm.max_decode_seq_len, self.kv_cache_dtype, self.num_kv_heads,
                                       self.scale, None, 1.0, 1.0, output=out[n0:])
-        if kv_cache is not None and n0 == 0 and not self.compat.per_layer_decision:
-            try:
-                launcher = ops.DecodeLayerLauncher(q, k, v, kv_cache, self.num_heads, self.num_kv_heads,
-                                                   self.head_size, dm.slot_mapping, zero_slots,
-                                                   block_tables, seq_lens_arg, dm.max_decode_seq_len,
-                                                   self.scale)
-                launcher.tables, launcher.zero = block_tables, zero_slots
-                step["launcher"] = launcher
-            except RuntimeError:
-                step["launcher"] = None
 
     def _decode_decision(self, meta, dm, value_cache) -> Dict[str, Any]:
         """Eviction decision of this decode step: taken by the first layer that runs and reused
@@ -644,7 +680,7 @@ class PagedEvictImpl(_ImplBase):
                 ids = mgr.get_req_block_tables(i)
                 slots.append(ids[random.randint(1, len(ids) - 2)] * bs + random.randint(0, bs - 1))
             if slots:
-                dec["zero_slots"] = torch.tensor(slots, dtype=torch.int64).to(dev, non_blocking=True)
+                dec["zero_slots"] = staging.upload([np.asarray(slots, dtype=np.int64)], dev)[0]
         elif method in ("streamingLLM", "streamingLLM-1"):
             need_zero = method == "streamingLLM-1" and any(o and not t for o, t in zip(over, trig))
             if any(trig) or need_zero:
@@ -657,8 +693,8 @@ class PagedEvictImpl(_ImplBase):
                 dec["host_rmv"] = {i: (mgr.get_reqid_and_seqid(i)[0], 1)
                                    for i, t in enumerate(trig) if t}
         elif any(trig):
-            nblk = torch.tensor([len(mgr.get_req_block_tables(i)) for i in range(len(seq_lens))],
-                                dtype=torch.int32).to(dev, non_blocking=True)
+            nblk = staging.upload_i32([len(mgr.get_req_block_tables(i))
+                                       for i in range(len(seq_lens))], dev)
             override = None
             if self.compat.random_victim:
                 ov = []
@@ -669,7 +705,7 @@ class PagedEvictImpl(_ImplBase):
                     n = len(mgr.get_req_block_tables(i))
                     end = 1 + cfg.topk_blocks if method == "local" else n - 1
                     ov.append(random.randint(1, end - 1))
-                override = torch.tensor(ov, dtype=torch.int32).to(dev, non_blocking=True)
+                override = staging.upload_i32(ov, dev)
                 rmv, tables, _ = ops.evict_select_compact(
                     dm.block_tables, dm.seq_lens_tensor, nblk, method, cfg.cache_budget, bs,
                     cfg.topk_blocks, victim_override=override,
@@ -689,8 +725,9 @@ class PagedEvictImpl(_ImplBase):
             else:
                 table = self._table(dev)
                 self._sync_rows(table)
-                rows = torch.tensor([table.row_of(mgr.get_reqid_and_seqid(i))
-                                     for i in range(len(seq_lens))], dtype=torch.int32).to(dev)
+                rows = staging.upload_i32([table.row_of(mgr.get_reqid_and_seqid(i))
+                                           for i in range(len(seq_lens))], dev)
+                table.flush_new_rows()
                 rmv, tables, _ = ops.evict_select_compact(
                     dm.block_tables, dm.seq_lens_tensor, nblk, method, cfg.cache_budget, bs,
                     cfg.topk_blocks, drop_victim_score=not self.compat.keep_victim_score,
@@ -703,6 +740,8 @@ class PagedEvictImpl(_ImplBase):
                     parallel.broadcast_victims(rmv, self.tp_group, 0)
                 dec["rmv"] = rmv
             dec["tables"] = tables
+            if dec["rmv"] is not None:
+                dec["readback"] = staging.AsyncReadback(dec["rmv"])
         if not self.compat.per_layer_decision:
             step["decode"] = dec
         return dec
@@ -717,7 +756,7 @@ def _layer_index(prefix: str) -> int:
 
 
 def _cumsum_t(lens, device) -> torch.Tensor:
-    return torch.tensor(list(accumulate(lens, initial=0)), dtype=torch.int32, device=device)
+    return staging.upload_i32(list(accumulate(lens, initial=0)), device)
 
 
 def get_attn_backend_for_eviction(cache_config) -> Optional[Type[PagedEvictBackend]]:

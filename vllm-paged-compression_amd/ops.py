@@ -415,6 +415,12 @@ def decode_step(out, query, key, value, key_cache, value_cache, slot_mapping, nu
 
 
 # --------------------------------------------------------------------------------------
+def _prewrap(fn, first: int, tail: tuple) -> tuple:
+    """``tail`` (arguments ``first``.. of ``fn``) as instances of the declared C types."""
+    types = fn.argtypes[first:first + len(tail)]
+    return tuple(a if a is None else t(a) for a, t in zip(tail, types))
+
+
 class DecodeLayerLauncher:
     """Pre-validated launcher of one decode layer (KV write + paged attention).
 
@@ -468,11 +474,16 @@ class DecodeLayerLauncher:
                          key.stride(0), value.stride(0), kv_cache.stride(1), kv_head_stride,
                          float(scale), int(max_seq_len), dt, _p(ws), 0 if ws is None else ws.numel(),
                          stream)
+        # constant arguments converted to their C types once: the per-layer foreign call then
+        # converts only the six tensor pointers
+        self._rc_tail = _prewrap(lib.pe_reshape_and_cache, 4, self._rc_tail)
+        self._pa_tail = _prewrap(lib.pe_paged_decode, 4, self._pa_tail)
+        self._fs_tail = _prewrap(lib.pe_decode_step, 6, self._fs_tail)
 
     @staticmethod
     def signature(query, key, value, kv_cache):
-        return (query.shape[0], query.stride(0), key.stride(0), value.stride(0), kv_cache.shape,
-                kv_cache.dtype, query.dtype, query.device, query.numel(), key.numel())
+        return (query.shape, query.stride(0), key.shape, key.stride(0), value.stride(0),
+                kv_cache.shape, kv_cache.dtype, query.dtype, query.device)
 
     def matches(self, query, key, value, kv_cache) -> bool:
         return self.sig == self.signature(query, key, value, kv_cache)
