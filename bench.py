@@ -258,6 +258,15 @@ def cpu_baseline(a, budget):
                   "(the reference's CPU backend has none)"}
 
 
+def workload_name(a, wl) -> str:
+    return (f"Llama-3-8B attention geometry (Hq {a.num_heads}, Hkv {a.num_kv_heads}, D "
+            f"{a.head_size}, {a.layers} layers), block {a.block_size}, {a.num_prompts} "
+            f"requests {a.input_len}->{a.output_len}, "
+            + (f"{'budget ' + str(wl.budget)} ({a.evict:.0%} eviction), prompt "
+               f"{a.prompt_evict_method} / decode {a.decode_evict_method}"
+               if wl.cfg is not None else "no eviction"))
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -308,14 +317,13 @@ def main():
         avg_b = sum(byts) / len(byts)
         ach = avg_b / avg_t / 1e9
         # HBM bytes per launch from the PMC passes kept under profiles/ (FETCH_SIZE x2 per the
-        # gfx950 correction + WRITE_SIZE), as a ratio to the algorithmic bytes of the profiled
-        # launch; applied only to the shape it was measured on
+        # gfx950 correction + WRITE_SIZE, averaged over the decode launches of this same bench
+        # command), as a ratio to the algorithmic bytes; applied only to the workload it was
+        # measured on
         traffic = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_decode_pmc.json")))
-            sh = pmc["shape"]
-            if (sh["batch"], sh["num_heads"], sh["num_kv_heads"], sh["head_size"], sh["block_size"]) == \
-                    (a.num_prompts, wl.Hq, wl.Hkv, a.head_size, a.block_size) and \
+            if pmc["workload"] == workload_name(a, wl) and \
                     abs(avg_b / pmc["algorithmic_bytes_per_launch"] - 1.0) < 0.05:
                 traffic = int(avg_b * pmc["traffic_over_algorithmic"])
         except Exception:
@@ -340,12 +348,7 @@ def main():
         "scaling": "strong" if tp else "weak", "vs_baseline": None, "dtype": "bf16",
         "data": "synthetic",
         "config": {
-            "workload": f"Llama-3-8B attention geometry (Hq {a.num_heads}, Hkv {a.num_kv_heads}, D "
-                        f"{a.head_size}, {a.layers} layers), block {a.block_size}, {a.num_prompts} "
-                        f"requests {a.input_len}->{a.output_len}, "
-                        + (f"{'budget ' + str(wl.budget)} ({a.evict:.0%} eviction), prompt "
-                           f"{a.prompt_evict_method} / decode {a.decode_evict_method}"
-                           if wl.cfg is not None else "no eviction"),
+            "workload": workload_name(a, wl),
             "step": "one full generation of the batch through prefill + decode attention of all layers",
             "parallelism": (f"tp{world}" if tp else f"dp{world}") if world > 1 else "single",
             "oproj_allreduce": bool(wl.allreduce), **kv},

@@ -71,6 +71,15 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void paged_decode_mfma_kernel(
   const int g = lane >> 4;   // lane group: tokens 4g..4g+3 of a block
   const int hc = lane & 15;  // query head within the group (column of S^T / O^T)
 
+  // Block-table window in registers: lane l holds entry tbl_base + l of the row.  The first
+  // window is requested before the sequence length is known (the row is max_num_blocks_per_seq
+  // entries wide whatever the length), so the length -> table -> K/V chain of dependent loads
+  // at the start of the kernel is one link shorter, and the main loop picks its block ids with
+  // v_readlane instead of a dependent global load per pair.
+  const int32_t* table = block_tables + (int64_t)seq * max_num_blocks_per_seq;
+  int tbl_base = 0;
+  int tbl_reg = lane < max_num_blocks_per_seq ? table[lane] : 0;
+
   // a length beyond what the table row can address is clamped (never read past the row)
   const int seq_len = min(seq_lens[seq], max_num_blocks_per_seq * BS);
   // Fused KV write: the step's new token (position seq_len-1) is taken from new_key/new_value
@@ -88,7 +97,14 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void paged_decode_mfma_kernel(
   const int pairs_per_split = (n_pairs + num_splits - 1) / num_splits;
   const int pair_begin = split * pairs_per_split;
   const int pair_end = min(n_pairs, pair_begin + pairs_per_split);
-  const int32_t* table = block_tables + (int64_t)seq * max_num_blocks_per_seq;
+  auto block_id = [&](int i) -> int64_t {  // i is wave-uniform and never decreases
+    if (i >= tbl_base + 64) {
+      tbl_base = i & ~63;
+      const int e = tbl_base + lane;
+      tbl_reg = e < max_num_blocks_per_seq ? table[e] : 0;
+    }
+    return __builtin_amdgcn_readlane(tbl_reg, i - tbl_base);
+  };
 
   // ---- Q fragments: B operand, lane holds Q[head hc][32*ks + 8g .. +8) ------------
   vec8 qf[KS];
@@ -118,8 +134,8 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void paged_decode_mfma_kernel(
   auto issue = [&](DecTile<T, HEAD_SIZE>& t, int pair) {
     const int ia = 2 * pair;
     const int ib = min(2 * pair + 1, n_blocks - 1);  // odd tail: re-read A's neighbour, masked
-    const int64_t pa = __builtin_amdgcn_readfirstlane(table[ia]);
-    const int64_t pb = __builtin_amdgcn_readfirstlane(table[ib]);
+    const int64_t pa = block_id(ia);
+    const int64_t pb = block_id(ib);
     const T* ka = key_cache + pa * kv_block_stride + head_off + k_lane_off;
     const T* kb = key_cache + pb * kv_block_stride + head_off + k_lane_off;
     const T* va = value_cache + pa * kv_block_stride + head_off + v_lane_off;
