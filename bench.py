@@ -97,7 +97,9 @@ class Workload:
             self.Hq, self.D, self.D ** -0.5, self.Hkv, None, None, "auto", None, None,
             cache_config=self.ccfg, prefix=f"model.layers.{i}.self_attn.attn",
             prompt_evict_method=a.prompt_evict_method if self.cfg is not None else None,
-            tp_group=tp_group, max_num_seqs=B, max_blocks_per_seq=4 * self.blocks_per_seq_full)
+            tp_group=tp_group, total_num_kv_heads=a.num_kv_heads,
+            kv_head_owner=tp_rank % max(1, tp_size // a.num_kv_heads) == 0,
+            max_num_seqs=B, max_blocks_per_seq=4 * self.blocks_per_seq_full)
             for i in range(a.layers)]
         g = torch.Generator(device=dev).manual_seed(1234 + tp_rank)
         sc = self.D ** -0.5
@@ -269,17 +271,27 @@ def workload_name(a, wl) -> str:
 
 def main():
     a = parse()
+    if os.environ.get("PE_BENCH_HANG_DUMP"):  # stacks of every thread if the run is still going then
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["PE_BENCH_HANG_DUMP"]), exit=True)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # PE_BENCH_DIST_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than
+    # ranks (ranks share devices, collectives go through the host); the measured runs use RCCL
+    backend = os.environ.get("PE_BENCH_DIST_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     n_gpus = world
     tp = a.mode == "tp" and world > 1
     import vllm_paged_compression_amd as pkg

@@ -211,6 +211,30 @@ int pe_block_score_value_l2(float* scores_out, const void* values,
                             int block_size, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * The same score in two steps, for head-sharded (tensor-parallel) caches: each rank holds
+ * num_kv_heads of the total_kv_heads KV heads, so the head mean of
+ * kvcache_prunner.py:51-56 spans ranks.
+ *   pe_block_token_norm_sums: sums_out[i*block_size + t] = sum over the LOCAL heads of the
+ *     (storage-type rounded) norms of token t of block i — f32, not rounded;
+ *   the caller adds the ranks' arrays (all-reduce, one f32 [n_blocks*block_size]
+ *     message);
+ *   pe_block_score_from_token_sums: scores_out[i] = round(sum_t round(sums[i][t] /
+ *     total_kv_heads)) with the rounding of the storage type.
+ * With every head on one rank the two steps give exactly pe_block_score_value_l2; across
+ * ranks they give the same bits whenever the f32 head sums are exact (norms are 8- or 11-bit
+ * significands, so always unless one token's norms span more than 2^13 across heads).
+ * Arguments as pe_block_score_value_l2 (PE_SCORE_CACHE_FLAT is not head-separable and is
+ * rejected).
+ * ---------------------------------------------------------------------------------- */
+int pe_block_token_norm_sums(float* sums_out, const void* values, const int32_t* block_ids,
+                             int n_blocks, int layout, int64_t block_stride,
+                             int num_kv_heads, int head_size, int block_size, int dtype,
+                             void* stream);
+int pe_block_score_from_token_sums(float* scores_out, const float* sums, int n_blocks,
+                                   int block_size, int total_kv_heads, int dtype,
+                                   void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Decode-step eviction decision + block-table compaction, one launch per step.
  * Replaces _prune_decode_reqs_streamingLLM / _prune_decode_reqs_topk /
  * _create_updated_block_tables (torch_cuda_sdpa.py:1375-1433,1478-1586) and the score
@@ -222,7 +246,9 @@ int pe_block_score_value_l2(float* scores_out, const void* values,
  *     reports, on non-boundary steps past the budget, the slot
  *     block_tables[b][1]*block_size + seq_len%block_size - 1 in zero_slots_out[b];
  *   local / global: the just-filled block (table entry num_blocks[b]-1) is scored from the
- *     value cache, appended to the sequence's score list
+ *     value cache (or taken from new_scores[b] when new_scores is non-NULL: the
+ *     tensor-parallel caller computes it with the two-step form above; value_cache may
+ *     then be NULL), appended to the sequence's score list
  *     score_table[score_rows[b]][0..score_counts[..]), and the victim is the first
  *     arg-min over [1, 1+topk_blocks) (local) or [1, n_scores-1) (global).  If
  *     victim_override is non-NULL and victim_override[b] >= 0 that index is used instead
@@ -247,7 +273,8 @@ int pe_evict_select_compact(int32_t* rmv_idx_out, int32_t* out_tables,
                             float* score_table, int32_t* score_counts,
                             const int32_t* score_rows, int score_table_width,
                             const void* value_cache, int64_t kv_block_stride,
-                            int num_kv_heads, int head_size, int dtype, void* stream);
+                            int num_kv_heads, int head_size, const float* new_scores,
+                            int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Block copy / swap — backend-API obligations (vllm/attention/backends/abstract.py:79-94).

@@ -304,6 +304,42 @@ float orc_block_score(const void* values, int block_size, int num_kv_heads,
 }
 
 /*
+ * The same score split at the head mean, for caches whose KV heads are spread over
+ * tensor-parallel ranks (each rank passes its own heads): orc_block_token_norm_sums gives,
+ * per token, the f32 sum over the given heads of the rounded norms; the ranks' arrays are
+ * added; orc_block_score_from_token_sums applies the mean over ALL heads, its rounding, the
+ * token sum and its rounding (kvcache_prunner.py:51-56 restated around an all-reduce).
+ */
+void orc_block_token_norm_sums(const void* values, float* sums, int block_size, int num_kv_heads,
+                               int head_size, int layout, int dtype) {
+  for (int t = 0; t < block_size; ++t) {
+    float head_sum = 0.f;
+    for (int h = 0; h < num_kv_heads; ++h) {
+      float ss = 0.f;
+      for (int d = 0; d < head_size; ++d) {
+        int64_t idx;
+        if (layout == 1)
+          idx = ((int64_t)h * head_size + d) * block_size + t;
+        else
+          idx = ((int64_t)t * num_kv_heads + h) * head_size + d;
+        const float v = load_elem(values, idx, dtype);
+        ss += v * v;
+      }
+      head_sum += round_to(sqrtf(ss), dtype);
+    }
+    sums[t] = head_sum;
+  }
+}
+
+float orc_block_score_from_token_sums(const float* sums, int block_size, int total_kv_heads,
+                                      int dtype) {
+  float tok_sum = 0.f;
+  for (int t = 0; t < block_size; ++t)
+    tok_sum += round_to(sums[t] / (float)total_kv_heads, dtype);
+  return round_to(tok_sum, dtype);
+}
+
+/*
  * Block-table compaction, intended semantics of
  * TorchCUDASDPABackendImpl._create_updated_block_tables,
  * vllm/attention/backends/torch_cuda_sdpa.py:1562-1586: row b loses column

@@ -53,6 +53,7 @@ def lib() -> ctypes.CDLL:
             build()
         L = ctypes.CDLL(_LIB_PATH)
         L.orc_block_score.restype = ctypes.c_float
+        L.orc_block_score_from_token_sums.restype = ctypes.c_float
         L.orc_bf16_to_f32.restype = ctypes.c_float
         L.orc_f16_to_f32.restype = ctypes.c_float
         L.orc_f32_to_bf16.restype = ctypes.c_uint16
@@ -125,6 +126,24 @@ def block_score(values: torch.Tensor, block_size: int, num_kv_heads: int, head_s
     return float(lib().orc_block_score(_p(values), ctypes.c_int(block_size),
                                        ctypes.c_int(num_kv_heads), ctypes.c_int(head_size),
                                        ctypes.c_int(layout), ctypes.c_int(_DT[values.dtype])))
+
+
+def block_token_norm_sums(values: torch.Tensor, block_size: int, num_kv_heads: int, head_size: int,
+                          layout: int) -> torch.Tensor:
+    """Per token of one block, the f32 sum over the given heads of the rounded norms."""
+    values = values.contiguous()
+    out = torch.zeros(block_size, dtype=torch.float32)
+    lib().orc_block_token_norm_sums(_p(values), _p(out), ctypes.c_int(block_size),
+                                    ctypes.c_int(num_kv_heads), ctypes.c_int(head_size),
+                                    ctypes.c_int(layout), ctypes.c_int(_DT[values.dtype]))
+    return out
+
+
+def block_score_from_token_sums(sums: torch.Tensor, total_kv_heads: int, dtype: torch.dtype) -> float:
+    sums = sums.to(torch.float32).contiguous()
+    return float(lib().orc_block_score_from_token_sums(_p(sums), ctypes.c_int(sums.numel()),
+                                                       ctypes.c_int(total_kv_heads),
+                                                       ctypes.c_int(_DT[dtype])))
 
 
 def compact_block_tables(tables: torch.Tensor, rmv_idx: Sequence[int], compat_q1: bool = False,

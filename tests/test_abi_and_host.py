@@ -40,7 +40,7 @@ def test_argument_checks_without_gpu():
                              0.1, 64, 2, None, 0, None)
     assert rc == 1 and b"null pointer" in lib.pe_last_error()
     rc = lib.pe_evict_select_compact(1, 1, None, 1, 1, 1, None, 2, 8, 7, 99, 128, 16, -1, 1, 0, 1,
-                                     None, None, None, 0, None, 0, 8, 128, 2, None)
+                                     None, None, None, 0, None, 0, 8, 128, None, 2, None)
     assert rc == 1 and b"unknown eviction method" in lib.pe_last_error()
     with pytest.raises(RuntimeError):
         _lib.check(rc, "evict_select_compact")

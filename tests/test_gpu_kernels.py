@@ -563,3 +563,80 @@ def test_decode_step_fused_write(ops, oracle, Hq, Hkv, D, dtype, splits, monkeyp
     ref = oracle.paged_attention(q, kc, vc, bt, lens_t, sc)
     assert torch.equal(kc_d.cpu(), kc) and torch.equal(vc_d.cpu(), vc)
     torch.testing.assert_close(out.cpu().float(), ref.float(), atol=ATOL[dtype], rtol=RTOL[dtype])
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("layout", [0, 1])
+def test_block_score_two_step_head_sharded(oracle, dtype, layout):
+    """pe_block_token_norm_sums + pe_block_score_from_token_sums: with all heads in one call they
+    equal pe_block_score_value_l2 and the oracle bit for bit; with the heads split over two or
+    four 'ranks' (sums added in f32, as the all-reduce does) they still do."""
+    from vllm_paged_compression_amd import ops
+    g = torch.Generator().manual_seed(5)
+    H, D, bs, nblk = 8, 128, 16, 7
+    if layout == 0:
+        vals = (torch.rand(nblk * bs, H, D, generator=g) * 2 - 1).to(dtype)
+        blocks = [vals[b * bs:(b + 1) * bs] for b in range(nblk)]
+    else:
+        vals = (torch.rand(nblk, H, D, bs, generator=g) * 2 - 1).to(dtype)
+        blocks = [vals[b] for b in range(nblk)]
+    dv = vals.cuda()
+    ids = None if layout == 0 else torch.arange(nblk, dtype=torch.int32, device="cuda")
+    stride = None if layout == 0 else dv.stride(0)
+    fused = ops.block_score_value_l2(dv, ids, nblk, layout, H, D, bs, block_stride=stride).cpu()
+    expect = torch.tensor([oracle.block_score(b, bs, H, D, layout) for b in blocks])
+    assert torch.equal(fused, expect)
+    sums = ops.block_token_norm_sums(dv, ids, nblk, layout, H, D, bs, block_stride=stride)
+    osums = torch.cat([oracle.block_token_norm_sums(b, bs, H, D, layout) for b in blocks])
+    assert torch.equal(sums.cpu(), osums)
+    two = ops.block_score_from_token_sums(sums, nblk, bs, H, dtype).cpu()
+    assert torch.equal(two, expect)
+    for ranks in (2, 4):
+        hl = H // ranks
+        total = torch.zeros(nblk * bs, dtype=torch.float32, device="cuda")
+        for r in range(ranks):
+            if layout == 0:
+                shard = dv[:, r * hl:(r + 1) * hl].contiguous()
+                st = None
+            else:
+                shard = dv[:, r * hl:(r + 1) * hl].contiguous()
+                st = shard.stride(0)
+            total += ops.block_token_norm_sums(shard, ids, nblk, layout, hl, D, bs, block_stride=st)
+        got = ops.block_score_from_token_sums(total, nblk, bs, H, dtype).cpu()
+        assert torch.equal(got, expect), ranks
+        assert oracle.block_score_from_token_sums(total[:bs].cpu(), H, dtype) == float(expect[0])
+
+
+def test_evict_select_compact_with_caller_scores(oracle):
+    """new_scores replaces the in-launch scoring of the just-filled block: same victims, tables
+    and score bookkeeping as the launch that scores from the value cache."""
+    from vllm_paged_compression_amd import ops
+    g = torch.Generator().manual_seed(9)
+    B, H, D, bs, nb, M = 4, 2, 64, 16, 64, 10
+    vc = (torch.rand(nb, H, D, bs, generator=g) * 2 - 1).to(torch.bfloat16).cuda()
+    tables = torch.stack([torch.randperm(nb, generator=g)[:M] for _ in range(B)]).to(torch.int32).cuda()
+    nblk = torch.tensor([10, 9, 10, 8], dtype=torch.int32).cuda()
+    seq_lens = torch.tensor([160, 144, 150, 128], dtype=torch.int32).cuda()   # row 2 not on a boundary
+    budget = 96
+
+    def fresh():
+        t = torch.rand(B, 32, generator=torch.Generator().manual_seed(1)).cuda()
+        c = (nblk - 1).clone()
+        return t, c
+
+    rows = torch.arange(B, dtype=torch.int32).cuda()
+    t1, c1 = fresh()
+    r1, o1, _ = ops.evict_select_compact(tables, seq_lens, nblk, "global", budget, bs, 3,
+                                         score_table=t1, score_counts=c1, score_rows=rows,
+                                         value_cache=vc, out_width=M - 1)
+    last = tables.gather(1, (nblk.long() - 1).unsqueeze(1)).squeeze(1).contiguous()
+    sums = ops.block_token_norm_sums(vc, last, B, 1, H, D, bs, block_stride=vc.stride(0))
+    ns = ops.block_score_from_token_sums(sums, B, bs, H, torch.bfloat16)
+    t2, c2 = fresh()
+    r2, o2, _ = ops.evict_select_compact(tables, seq_lens, nblk, "global", budget, bs, 3,
+                                         score_table=t2, score_counts=c2, score_rows=rows,
+                                         value_cache=None, out_width=M - 1, new_scores=ns,
+                                         dtype=torch.bfloat16)
+    assert torch.equal(r1, r2) and torch.equal(o1, o2)
+    assert torch.equal(t1, t2) and torch.equal(c1, c2)
+    assert (r1.cpu() >= 0).sum() == 3 and r1[2].item() == -1

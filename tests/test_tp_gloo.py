@@ -49,7 +49,15 @@ def _worker(rank, world, port, q):
         part = local.float().reshape(3, -1) @ wo[sh.q_head_start * D:(sh.q_head_start + sh.num_heads) * D]
         parallel.all_reduce_sum(part)
         torch.testing.assert_close(part, full.float().reshape(3, -1) @ wo, atol=1e-4, rtol=1e-4)
-        # data-dependent victims: each rank scores with its own heads, rank 0's choice is used
+        # value_l2 scores over ALL heads from head-sharded caches: per-token sums of this rank's
+        # heads, added over the ranks, then the head mean / token sum with their roundings -
+        # bit-identical to scoring the unsharded block, on every rank
+        for b in range(nb):
+            sums = oracle.block_token_norm_sums(vs[b], bs, sh.num_kv_heads, D, 1)
+            parallel.all_reduce_sum(sums)
+            s_tp = oracle.block_score_from_token_sums(sums, Hkv, torch.bfloat16)
+            assert s_tp == oracle.block_score(vc[b], bs, Hkv, D, 1), (b, s_tp)
+        # reference-compatible fallback: each rank scores with its own heads, rank 0's choice is used
         scores = [oracle.block_score(vs[b], bs, 1, D, 1) for b in range(6)]
         mine = oracle.argmin_first(scores, 1, 5)
         rmv = torch.tensor([mine, -1, mine], dtype=torch.int32)

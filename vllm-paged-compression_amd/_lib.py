@@ -42,10 +42,15 @@ SIGNATURES = {
                                        c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
     "pe_block_score_value_l2": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64,
                                         c_int, c_int, c_int, c_int, c_void_p]),
+    "pe_block_token_norm_sums": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64,
+                                         c_int, c_int, c_int, c_int, c_void_p]),
+    "pe_block_score_from_token_sums": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                               c_void_p]),
     "pe_evict_select_compact": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                         c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
-                                        c_int, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+                                        c_int, c_void_p, c_int64, c_int, c_int, c_void_p, c_int,
+                                        c_void_p]),
     "pe_copy_blocks": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int,
                                c_void_p]),
     "pe_swap_blocks": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),

@@ -436,6 +436,11 @@ class PagedEvictImpl(_ImplBase):
         self._pending_readback: Optional[staging.AsyncReadback] = None
         self._pending_reqs: Optional[List[str]] = None
         self._score_table: Optional[DeviceScoreTable] = None
+        # tensor parallel: KV heads of the whole model, and whether this rank is the one that
+        # accounts for its KV heads when they are replicated (more ranks than KV heads)
+        self.total_num_kv_heads = int(kwargs.get("total_num_kv_heads", 0)) or (
+            self.num_kv_heads * (parallel.group_size(self.tp_group) if self.tp_group is not None else 1))
+        self.kv_head_owner = bool(kwargs.get("kv_head_owner", True))
         self.max_num_seqs = int(kwargs.get("max_num_seqs", 256))
         self.max_blocks_per_seq = int(kwargs.get("max_blocks_per_seq", 4096))
 
@@ -568,8 +573,20 @@ class PagedEvictImpl(_ImplBase):
     def _tp_size(self) -> int:
         return parallel.group_size(self.tp_group) if self.tp_group is not None else 1
 
+    def _tp_exact_scores(self) -> bool:
+        """Tensor parallel with rank-invariant scores: every rank keeps the full-head score table
+        (token sums all-reduced).  The flat cache view mixes heads and tokens of the local shard,
+        so that compatibility mode falls back to rank 0 deciding and broadcasting."""
+        return self._tp_size() > 1 and not self.compat.score_flat_cache_view
+
+    def _reduce_token_sums(self, sums: torch.Tensor) -> torch.Tensor:
+        if not self.kv_head_owner:
+            sums.zero_()
+        return parallel.all_reduce_sum(sums, self.tp_group)
+
     def _needs_scores(self) -> bool:
-        if self._tp_size() > 1 and parallel.group_rank(self.tp_group) != 0:
+        if self._tp_size() > 1 and not self._tp_exact_scores() \
+                and parallel.group_rank(self.tp_group) != 0:
             return False
         return (self.enabled_paged_eviction and not self.compat.random_victim
                 and self.paged_evict_config.evict_method in ("local", "global")
@@ -590,15 +607,36 @@ class PagedEvictImpl(_ImplBase):
         self._sync_rows(table)
         off = 0
         rows, counts = [], []
+        exact_tp = self._tp_exact_scores()
+        H, D = values.shape[1], values.shape[2]
+        if exact_tp:
+            sums = torch.empty(sum(n // bs for n in kept) * bs, dtype=torch.float32,
+                               device=values.device)
+            so = 0
         for i, n in enumerate(kept):
             nb = n // bs
             row = table.row_of(self.block_l2norm_mgr.get_reqid_and_seqid(i))
             if nb > 0:
-                self.kv_cache_pruner.get_block_scores_dense(values[off:off + nb * bs], nb,
-                                                            out=table.scores[row, :nb])
+                if exact_tp:
+                    ops.block_token_norm_sums(values[off:off + nb * bs], None, nb,
+                                              ops.SCORE_TOKEN_MAJOR, H, D, bs,
+                                              out=sums[so:so + nb * bs])
+                    so += nb * bs
+                else:
+                    self.kv_cache_pruner.get_block_scores_dense(values[off:off + nb * bs], nb,
+                                                                out=table.scores[row, :nb])
             rows.append(row)
             counts.append(nb)
             off += n
+        if exact_tp and sums.numel():
+            self._reduce_token_sums(sums)
+            so = 0
+            for row, nb in zip(rows, counts):
+                if nb > 0:
+                    ops.block_score_from_token_sums(sums[so:so + nb * bs], nb, bs,
+                                                    self.total_num_kv_heads, values.dtype,
+                                                    out=table.scores[row, :nb])
+                    so += nb * bs
         table.set_counts(rows, counts)
 
     def _sync_rows(self, table: DeviceScoreTable) -> None:
@@ -712,7 +750,8 @@ class PagedEvictImpl(_ImplBase):
                     compat_q1=self.compat.block_table_slice_in_loop, out_width=width)
                 dec["host_rmv"] = {i: (mgr.get_reqid_and_seqid(i)[0], r)
                                    for i, r in enumerate(ov) if r >= 0}
-            elif self._tp_size() > 1 and parallel.group_rank(self.tp_group) != 0:
+            elif self._tp_size() > 1 and not self._tp_exact_scores() \
+                    and parallel.group_rank(self.tp_group) != 0:
                 # data-dependent victims are decided by the first rank of the TP group and
                 # broadcast; this rank only applies them
                 rmv = torch.empty(len(seq_lens), dtype=torch.int32, device=dev)
@@ -728,6 +767,19 @@ class PagedEvictImpl(_ImplBase):
                 rows = staging.upload_i32([table.row_of(mgr.get_reqid_and_seqid(i))
                                            for i in range(len(seq_lens))], dev)
                 table.flush_new_rows()
+                new_scores = None
+                if self._tp_exact_scores():
+                    # score of each sequence's just-filled block over ALL KV heads: local token
+                    # sums -> all-reduce -> finish; identical on every rank, so no broadcast
+                    B = len(seq_lens)
+                    last = dm.block_tables.gather(
+                        1, (nblk.to(torch.int64) - 1).clamp_(min=0).unsqueeze(1)).squeeze(1).contiguous()
+                    sums = ops.block_token_norm_sums(value_cache, last, B, ops.SCORE_CACHE,
+                                                     value_cache.shape[1], value_cache.shape[2], bs,
+                                                     block_stride=value_cache.stride(0))
+                    self._reduce_token_sums(sums)
+                    new_scores = ops.block_score_from_token_sums(sums, B, bs, self.total_num_kv_heads,
+                                                                 value_cache.dtype)
                 rmv, tables, _ = ops.evict_select_compact(
                     dm.block_tables, dm.seq_lens_tensor, nblk, method, cfg.cache_budget, bs,
                     cfg.topk_blocks, drop_victim_score=not self.compat.keep_victim_score,
@@ -735,8 +787,8 @@ class PagedEvictImpl(_ImplBase):
                     score_layout=(ops.SCORE_CACHE_FLAT if self.compat.score_flat_cache_view
                                   else ops.SCORE_CACHE),
                     score_table=table.scores, score_counts=table.counts, score_rows=rows,
-                    value_cache=value_cache, out_width=width)
-                if self._tp_size() > 1:
+                    value_cache=value_cache, out_width=width, new_scores=new_scores)
+                if self._tp_size() > 1 and new_scores is None:
                     parallel.broadcast_victims(rmv, self.tp_group, 0)
                 dec["rmv"] = rmv
             dec["tables"] = tables

@@ -1,5 +1,7 @@
 // Eviction scoring and the per-step eviction decision on gfx950:
 //   pe_block_score_value_l2   per-block value_l2 score
+//   pe_block_token_norm_sums / pe_block_score_from_token_sums   the same score in two steps
+//                             around an all-reduce, for head-sharded caches
 //   pe_evict_select_compact   trigger + victim choice + score bookkeeping + block-table
 //                             compaction (+ streamingLLM-1 zero-slot ids), one launch/step
 // Integer / small-FP work: one 64-lane wave per block or per sequence; the byte traffic is
@@ -69,6 +71,58 @@ __global__ __launch_bounds__(64) void block_score_kernel(float* __restrict__ sco
   if (threadIdx.x == 0) scores[i] = s;
 }
 
+// Head-sharded scoring, step 1: per token, the sum over this rank's heads of the rounded norms.
+template <typename T>
+__global__ __launch_bounds__(64) void block_token_norm_sums_kernel(
+    float* __restrict__ sums, const T* __restrict__ values, const int32_t* __restrict__ block_ids,
+    int layout, int64_t block_stride, int num_kv_heads, int head_size, int block_size) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* norms = reinterpret_cast<float*>(smem);
+  const int lane = threadIdx.x;
+  const int i = blockIdx.x;
+  const int64_t blk = block_ids ? block_ids[i] : i;
+  const T* base = values + blk * block_stride;
+  const int pairs = block_size * num_kv_heads;
+  for (int p = lane; p < pairs; p += 64) {
+    const int t = p / num_kv_heads, h = p % num_kv_heads;
+    float ss = 0.f;
+    if (layout == PE_SCORE_CACHE) {
+      const T* v = base + (int64_t)h * head_size * block_size + t;
+      for (int d = 0; d < head_size; ++d) {
+        const float x = to_f32(v[(int64_t)d * block_size]);
+        ss += x * x;
+      }
+    } else {
+      const T* v = base + (int64_t)p * head_size;
+      for (int d = 0; d < head_size; ++d) {
+        const float x = to_f32(v[d]);
+        ss += x * x;
+      }
+    }
+    norms[p] = round_to<T>(sqrtf(ss));
+  }
+  __syncthreads();
+  for (int t = lane; t < block_size; t += 64) {
+    float hs = 0.f;
+    for (int h = 0; h < num_kv_heads; ++h) hs += norms[t * num_kv_heads + h];
+    sums[(int64_t)i * block_size + t] = hs;
+  }
+}
+
+// Step 2: head mean over all ranks' heads, rounded; token sum, rounded.
+template <typename T>
+__global__ __launch_bounds__(64) void block_score_from_sums_kernel(float* __restrict__ scores,
+                                                                   const float* __restrict__ sums,
+                                                                   int n_blocks, int block_size,
+                                                                   int total_kv_heads) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n_blocks) return;
+  float total = 0.f;
+  for (int t = 0; t < block_size; ++t)
+    total += round_to<T>(sums[(int64_t)i * block_size + t] / (float)total_kv_heads);
+  scores[i] = round_to<T>(total);
+}
+
 // One wave per sequence (grid = batch), or a single wave walking all rows serially when the
 // reference's in-loop slice has to be reproduced (compat_q1).
 template <typename T>
@@ -80,7 +134,8 @@ __global__ __launch_bounds__(64) void evict_select_compact_kernel(
     int method, int cache_budget, int block_size, int topk_blocks, int drop_victim_score, int compat_q1,
     int score_layout, float* __restrict__ score_table, int32_t* __restrict__ score_counts,
     const int32_t* __restrict__ score_rows, int score_table_width,
-    const T* __restrict__ value_cache, int64_t kv_block_stride, int num_kv_heads, int head_size) {
+    const T* __restrict__ value_cache, int64_t kv_block_stride, int num_kv_heads, int head_size,
+    const float* __restrict__ new_scores) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* norms = reinterpret_cast<float*>(smem);
   float* means = norms + block_size * num_kv_heads;
@@ -109,10 +164,14 @@ __global__ __launch_bounds__(64) void evict_select_compact_kernel(
           const int srow = score_rows[b];
           float* list = score_table + (int64_t)srow * score_table_width;
           int n = score_counts[srow];
-          const int last_blk = row[num_blocks[b] - 1];
-          const float s = block_score_wave<T>(value_cache + (int64_t)last_blk * kv_block_stride,
-                                              score_layout, num_kv_heads, head_size, block_size,
-                                              norms, means);
+          float s;
+          if (new_scores != nullptr) {
+            s = new_scores[b];  // scored by the caller (head-sharded caches)
+          } else {
+            const int last_blk = row[num_blocks[b] - 1];
+            s = block_score_wave<T>(value_cache + (int64_t)last_blk * kv_block_stride, score_layout,
+                                    num_kv_heads, head_size, block_size, norms, means);
+          }
           // the appended entry is kept in a register (every lane holds s): entries written
           // in this launch are never read back through memory
           int n_new = -1;
@@ -221,6 +280,44 @@ int pe_block_score_value_l2(float* scores_out, const void* values, const int32_t
   return check_launch("block_score_value_l2");
 }
 
+int pe_block_token_norm_sums(float* sums_out, const void* values, const int32_t* block_ids,
+                             int n_blocks, int layout, int64_t block_stride, int num_kv_heads,
+                             int head_size, int block_size, int dtype, void* stream) {
+  using namespace pe;
+  PE_REQUIRE(n_blocks >= 0, PE_ERR_INVALID_ARG, "negative n_blocks");
+  if (n_blocks == 0) return PE_OK;
+  PE_REQUIRE(sums_out && values, PE_ERR_INVALID_ARG, "block_token_norm_sums: null pointer");
+  PE_REQUIRE(layout == PE_SCORE_TOKEN_MAJOR || layout == PE_SCORE_CACHE, PE_ERR_INVALID_ARG,
+             "block_token_norm_sums: layout %d is not head-separable", layout);
+  PE_REQUIRE(num_kv_heads > 0 && head_size > 0 && block_size > 0, PE_ERR_INVALID_ARG,
+             "block_token_norm_sums: bad sizes");
+  PE_REQUIRE(block_size * num_kv_heads <= SCORE_MAX_PAIRS, PE_ERR_UNSUPPORTED,
+             "block_size*num_kv_heads too large for the score kernel");
+  const size_t lds = (size_t)(block_size * num_kv_heads) * 4;
+  PE_DISPATCH_ALL(dtype, T,
+                  hipLaunchKernelGGL(block_token_norm_sums_kernel<T>, dim3((unsigned)n_blocks),
+                                     dim3(64), lds, static_cast<hipStream_t>(stream), sums_out,
+                                     (const T*)values, block_ids, layout, block_stride, num_kv_heads,
+                                     head_size, block_size));
+  return check_launch("block_token_norm_sums");
+}
+
+int pe_block_score_from_token_sums(float* scores_out, const float* sums, int n_blocks,
+                                   int block_size, int total_kv_heads, int dtype, void* stream) {
+  using namespace pe;
+  PE_REQUIRE(n_blocks >= 0, PE_ERR_INVALID_ARG, "negative n_blocks");
+  if (n_blocks == 0) return PE_OK;
+  PE_REQUIRE(scores_out && sums, PE_ERR_INVALID_ARG, "block_score_from_token_sums: null pointer");
+  PE_REQUIRE(block_size > 0 && total_kv_heads > 0, PE_ERR_INVALID_ARG,
+             "block_score_from_token_sums: bad sizes");
+  PE_DISPATCH_ALL(dtype, T,
+                  hipLaunchKernelGGL(block_score_from_sums_kernel<T>,
+                                     dim3((unsigned)((n_blocks + 63) / 64)), dim3(64), 0,
+                                     static_cast<hipStream_t>(stream), scores_out, sums, n_blocks,
+                                     block_size, total_kv_heads));
+  return check_launch("block_score_from_token_sums");
+}
+
 int pe_evict_select_compact(int32_t* rmv_idx_out, int32_t* out_tables, int64_t* zero_slots_out,
                             const int32_t* block_tables, const int32_t* seq_lens,
                             const int32_t* num_blocks, const int32_t* victim_override, int batch,
@@ -229,7 +326,7 @@ int pe_evict_select_compact(int32_t* rmv_idx_out, int32_t* out_tables, int64_t* 
                             int score_layout, float* score_table, int32_t* score_counts,
                             const int32_t* score_rows, int score_table_width,
                             const void* value_cache, int64_t kv_block_stride, int num_kv_heads,
-                            int head_size, int dtype, void* stream) {
+                            int head_size, const float* new_scores, int dtype, void* stream) {
   using namespace pe;
   PE_REQUIRE(batch >= 0, PE_ERR_INVALID_ARG, "negative batch");
   if (batch == 0) return PE_OK;
@@ -253,13 +350,15 @@ int pe_evict_select_compact(int32_t* rmv_idx_out, int32_t* out_tables, int64_t* 
     PE_REQUIRE(score_table || victim_override, PE_ERR_INVALID_ARG,
                "local/global need a score table or host-chosen victims");
     if (score_table) {
-      PE_REQUIRE(score_counts && score_rows && value_cache && score_table_width > 2,
+      PE_REQUIRE(score_counts && score_rows && (value_cache || new_scores) && score_table_width > 2,
                  PE_ERR_INVALID_ARG, "score bookkeeping arguments missing");
-      PE_REQUIRE(num_kv_heads > 0 && head_size > 0 && block_size * num_kv_heads <= SCORE_MAX_PAIRS,
-                 PE_ERR_INVALID_ARG, "bad head layout for block scoring");
-      PE_REQUIRE(score_layout == PE_SCORE_CACHE || score_layout == PE_SCORE_CACHE_FLAT,
-                 PE_ERR_INVALID_ARG, "decode-time scores read the paged cache (layout 1 or 2)");
-      lds = (size_t)(block_size * num_kv_heads + block_size) * 4;
+      if (!new_scores) {
+        PE_REQUIRE(num_kv_heads > 0 && head_size > 0 && block_size * num_kv_heads <= SCORE_MAX_PAIRS,
+                   PE_ERR_INVALID_ARG, "bad head layout for block scoring");
+        PE_REQUIRE(score_layout == PE_SCORE_CACHE || score_layout == PE_SCORE_CACHE_FLAT,
+                   PE_ERR_INVALID_ARG, "decode-time scores read the paged cache (layout 1 or 2)");
+        lds = (size_t)(block_size * num_kv_heads + block_size) * 4;
+      }
     }
   }
   const unsigned grid = compat_q1 ? 1u : (unsigned)batch;
@@ -271,7 +370,7 @@ int pe_evict_select_compact(int32_t* rmv_idx_out, int32_t* out_tables, int64_t* 
                                      block_size, topk_blocks, drop_victim_score, compat_q1,
                                      score_layout, score_table, score_counts, score_rows,
                                      score_table_width, (const T*)value_cache, kv_block_stride,
-                                     num_kv_heads, head_size));
+                                     num_kv_heads, head_size, new_scores));
   return check_launch("evict_select_compact");
 }
 

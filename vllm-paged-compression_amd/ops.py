@@ -329,6 +329,42 @@ def block_score_value_l2(values: torch.Tensor, block_ids: Optional[torch.Tensor]
     return out
 
 
+def block_token_norm_sums(values: torch.Tensor, block_ids: Optional[torch.Tensor], n_blocks: int,
+                          layout: int, num_kv_heads: int, head_size: int, block_size: int,
+                          block_stride: Optional[int] = None,
+                          out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Step 1 of the head-sharded score: f32 [n_blocks * block_size], per token the sum over the
+    local heads of the rounded norms (to be summed over the tensor-parallel ranks)."""
+    dev = _need_gpu(values, block_ids)
+    if out is None:
+        out = torch.empty(n_blocks * block_size, dtype=torch.float32, device=dev)
+    if block_stride is None:
+        block_stride = block_size * num_kv_heads * head_size
+    lib = _lib.load()
+    _lib.check(lib.pe_block_token_norm_sums(_p(out), _p(values), _p(block_ids), n_blocks, layout,
+                                            block_stride, num_kv_heads, head_size, block_size,
+                                            _dtype_code(values), _stream(dev)),
+               "block_token_norm_sums")
+    return out
+
+
+def block_score_from_token_sums(sums: torch.Tensor, n_blocks: int, block_size: int,
+                                total_kv_heads: int, dtype: torch.dtype,
+                                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Step 2: scores f32 [n_blocks] from the rank-summed token sums; ``dtype`` is the cache's
+    storage type (its rounding is applied to the head mean and to the token sum)."""
+    dev = _need_gpu(sums)
+    if sums.dtype != torch.float32 or not sums.is_contiguous() or sums.numel() < n_blocks * block_size:
+        raise RuntimeError("block_score_from_token_sums: contiguous f32 [n_blocks*block_size] expected")
+    if out is None:
+        out = torch.empty(n_blocks, dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    _lib.check(lib.pe_block_score_from_token_sums(_p(out), _p(sums), n_blocks, block_size,
+                                                  total_kv_heads, _DT[dtype], _stream(dev)),
+               "block_score_from_token_sums")
+    return out
+
+
 def evict_select_compact(block_tables: torch.Tensor, seq_lens: torch.Tensor,
                          num_blocks: torch.Tensor, method: str, cache_budget: int,
                          block_size: int, topk_blocks: int = -1, *,
@@ -339,12 +375,16 @@ def evict_select_compact(block_tables: torch.Tensor, seq_lens: torch.Tensor,
                          score_counts: Optional[torch.Tensor] = None,
                          score_rows: Optional[torch.Tensor] = None,
                          value_cache: Optional[torch.Tensor] = None,
-                         compact: bool = True, out_width: Optional[int] = None):
+                         compact: bool = True, out_width: Optional[int] = None,
+                         new_scores: Optional[torch.Tensor] = None,
+                         dtype: Optional[torch.dtype] = None):
     """One launch per decode step: returns (rmv_idx int32[B], compacted tables int32[B, out_width]
     or None, zero_slots int64[B] or None).  out_width defaults to the reference's M-1; pass the
-    longest surviving row when a row that evicts nothing may be M blocks long."""
+    longest surviving row when a row that evicts nothing may be M blocks long.  ``new_scores``
+    (f32 [B]): scores of the just-filled blocks computed by the caller (head-sharded caches)
+    instead of in the launch."""
     dev = _need_gpu(block_tables, seq_lens, num_blocks, victim_override, score_table,
-                    score_counts, score_rows, value_cache)
+                    score_counts, score_rows, value_cache, new_scores)
     B, M = block_tables.shape
     for t in (block_tables, seq_lens, num_blocks):
         if t.dtype != torch.int32 or not t.is_contiguous():
@@ -361,9 +401,13 @@ def evict_select_compact(block_tables: torch.Tensor, seq_lens: torch.Tensor,
     width = 0
     if m in (2, 3):
         if victim_override is None or score_table is not None:
-            if score_table is None or score_counts is None or score_rows is None or value_cache is None:
+            if score_table is None or score_counts is None or score_rows is None or \
+                    (value_cache is None and new_scores is None):
                 raise RuntimeError("evict_select_compact: local/global need score_table, "
-                                   "score_counts, score_rows and value_cache")
+                                   "score_counts, score_rows and value_cache (or new_scores)")
+        if new_scores is not None and (new_scores.dtype != torch.float32 or new_scores.numel() != B
+                                       or not new_scores.is_contiguous()):
+            raise RuntimeError("evict_select_compact: new_scores must be contiguous f32 [batch]")
         if value_cache is not None:
             _, Hkv, D, bs = value_cache.shape
             if bs != block_size:
@@ -377,8 +421,9 @@ def evict_select_compact(block_tables: torch.Tensor, seq_lens: torch.Tensor,
         _p(rmv), _p(out_tables), _p(zero), _p(block_tables), _p(seq_lens), _p(num_blocks),
         _p(victim_override), B, M, out_width, m, cache_budget, block_size, topk_blocks,
         1 if drop_victim_score else 0, 1 if compat_q1 else 0, score_layout, _p(score_table),
-        _p(score_counts), _p(score_rows), width, _p(value_cache), kv_stride, Hkv, D, dt,
-        _stream(dev)), "evict_select_compact")
+        _p(score_counts), _p(score_rows), width, _p(value_cache), kv_stride, Hkv, D,
+        _p(new_scores), dt if dtype is None else _DT[dtype], _stream(dev)),
+        "evict_select_compact")
     return rmv, out_tables, zero
 
 

@@ -6,11 +6,16 @@ vllm/model_executor/models/llama.py:117-130); block tables, slot mappings and kv
 replicated.  The exchange steps are
   * the all-reduce (sum) of the row-parallel o_proj output that follows attention
     (vllm/model_executor/layers/linear.py:1099-1100), and
-  * making every rank evict the same block when the victim depends on data (value_l2
-    scores are computed from local heads): the deciding rank's indices are broadcast,
-    which is what the reference effectively does by committing only the driver rank's
-    layer-0 decision (vllm/worker/model_runner.py:1797-1802).
-Both use torch.distributed (backend "nccl" = RCCL over xGMI on the GPUs, "gloo" in CPU tests).
+  * making every rank evict the same block when the victim depends on data and the scores are
+    not rank-invariant (the reference-compatible flat cache view): the deciding rank's indices
+    are broadcast, which is what the reference effectively does by committing only the driver
+    rank's layer-0 decision (vllm/worker/model_runner.py:1797-1802);
+  * value_l2 scores average over ALL KV heads: each rank sums the norms of its heads per token,
+    the f32 token sums are all-reduced and every rank finishes the score itself
+    (``all_reduce_sum`` on the f32 sums), so all ranks hold identical score tables and take
+    identical decisions - the same ones a single GPU takes.
+Both use torch.distributed (backend "nccl" = RCCL over xGMI on the GPUs, "gloo" in CPU tests; a
+GPU tensor handed to a gloo group is staged through the host).
 """
 from __future__ import annotations
 
@@ -64,16 +69,30 @@ def broadcast_victims(rmv_idx: torch.Tensor, group: Optional[dist.ProcessGroup] 
                       src: int = 0) -> torch.Tensor:
     """Make every rank of the group use rank ``src``'s victim indices (int32 [batch], -1 = none)."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.broadcast(rmv_idx, src=dist.get_global_rank(group, src) if group is not None else src,
-                       group=group)
+        root = dist.get_global_rank(group, src) if group is not None else src
+        if _host_staged(rmv_idx, group):
+            tmp = rmv_idx.cpu()
+            dist.broadcast(tmp, src=root, group=group)
+            rmv_idx.copy_(tmp)
+        else:
+            dist.broadcast(rmv_idx, src=root, group=group)
     return rmv_idx
 
 
 def all_reduce_sum(x: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
     """In-place sum over the tensor-parallel group (the o_proj partial-output reduction)."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(x, op=dist.ReduceOp.SUM, group=group)
+        if _host_staged(x, group):
+            tmp = x.cpu()
+            dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=group)
+            x.copy_(tmp)
+        else:
+            dist.all_reduce(x, op=dist.ReduceOp.SUM, group=group)
     return x
+
+
+def _host_staged(x: torch.Tensor, group: Optional[dist.ProcessGroup]) -> bool:
+    return x.is_cuda and dist.get_backend(group) == "gloo"
 
 
 def group_rank(group: Optional[dist.ProcessGroup] = None) -> int:
