@@ -17,8 +17,13 @@ def main():
     ap.add_argument("--hkv", type=int, default=8)
     ap.add_argument("--d", type=int, default=128)
     ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--fused", action="store_true", help="time pe_decode_step (KV write fused)")
+    ap.add_argument("--lib", default=None, help="alternative build of the library (A/B timing)")
     ap.add_argument("--layers", type=int, default=32, help="distinct caches cycled through (defeats L2/MALL reuse)")
     a = ap.parse_args()
+    if a.lib:
+        import vllm_paged_compression_amd._lib as _lib
+        _lib.LIB_PATH = os.path.abspath(a.lib)
     dev = torch.device("cuda:0")
     bs = 16
     nblk_seq = (a.kv + bs - 1) // bs
@@ -35,9 +40,29 @@ def main():
     out = torch.empty_like(q)
     scale = a.d ** -0.5
 
+    k_new = torch.empty(a.batch, a.hkv, a.d, dtype=torch.bfloat16, device=dev).uniform_(-0.09, 0.09)
+    v_new = torch.empty(a.batch, a.hkv, a.d, dtype=torch.bfloat16, device=dev).uniform_(-0.09, 0.09)
+    slots = bt[:, (a.kv - 1) // bs].to(torch.int64) * bs + (a.kv - 1) % bs
+
+    launcher = None
+    if a.fused:
+        kvs = [torch.stack([kc.view(nb, -1), vc.view(nb, -1)]) for kc, vc in caches]
+        caches = None
+        launcher = ops.DecodeLayerLauncher(q.view(a.batch, -1), k_new.view(a.batch, -1),
+                                           v_new.view(a.batch, -1), kvs[0], a.hq, a.hkv, a.d, slots,
+                                           None, bt, lens, a.kv, scale)
+        assert launcher.fused
+        q2, k2, v2, o2 = q.view(a.batch, -1), k_new.view(a.batch, -1), v_new.view(a.batch, -1), out.view(a.batch, -1)
+
     def run(i):
+        if launcher is not None:
+            launcher.run(q2, k2, v2, kvs[i % a.layers], o2)
+            return
         kc, vc = caches[i % a.layers]
-        ops.paged_attention_v1(out, q, kc, vc, a.hkv, scale, bt, lens, bs, a.kv, None, "auto", 1.0, 1.0)
+        if False:
+            pass
+        else:
+            ops.paged_attention_v1(out, q, kc, vc, a.hkv, scale, bt, lens, bs, a.kv, None, "auto", 1.0, 1.0)
 
     for i in range(a.layers):
         run(i)
