@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--d", type=int, default=128)
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--fused", action="store_true", help="time pe_decode_step (KV write fused)")
+    ap.add_argument("--sequential", action="store_true", help="block tables in address order")
     ap.add_argument("--lib", default=None, help="alternative build of the library (A/B timing)")
     ap.add_argument("--layers", type=int, default=32, help="distinct caches cycled through (defeats L2/MALL reuse)")
     a = ap.parse_args()
@@ -36,6 +37,8 @@ def main():
         caches.append((kc, vc))
     q = torch.empty(a.batch, a.hq, a.d, dtype=torch.bfloat16, device=dev).uniform_(-0.09, 0.09)
     bt = torch.randperm(nb - 8, device=dev)[:a.batch * nblk_seq].to(torch.int32).reshape(a.batch, nblk_seq)
+    if a.sequential:
+        bt = torch.arange(a.batch * nblk_seq, device=dev, dtype=torch.int32).reshape(a.batch, nblk_seq)
     lens = torch.full((a.batch,), a.kv, dtype=torch.int32, device=dev)
     out = torch.empty_like(q)
     scale = a.d ** -0.5
