@@ -99,6 +99,46 @@ def main():
                 case += 1
     np.savez_compressed(os.path.join(HERE, "prompt_prune_topk.npz"), **out)
 
+    # ---- (i-b) the same at the benchmark's sizes: [L, 8, 128] and [L, 12, 64] ---------------
+    # The inputs are regenerated from their seed; stored are the SHA-256 of the reference's
+    # outputs and, per head, the bitmap of middle tokens it kept.  f32 inputs are tie-free and
+    # must match exactly; 16-bit inputs have tied scores (torch.topk's choice among ties is
+    # not specified), so for them the tests compare the kept scores, not the kept indices.
+    import hashlib
+    out = {}
+    case = 0
+    for method in ("global", "inverse_key_l2"):
+        for (L, budget, H, D, dtype) in [(1024, 768, 8, 128, torch.float32), (1030, 512, 8, 128, torch.float32),
+                                         (1024, 512, 12, 64, torch.float32),
+                                         (1024, 768, 8, 128, torch.bfloat16), (1030, 512, 12, 64, torch.float16)]:
+            bs = 16
+            g = torch.Generator().manual_seed(5000 + case)
+            k = (torch.rand(L, H, D, generator=g) * 2 - 1).to(dtype)
+            v = (torch.rand(L, H, D, generator=g) * 2 - 1).to(dtype)
+            p = kp.KVCachePruner("budget", method, bs, budget, 1)
+            pk, pv = p.prune_prompt(k, v)
+            assert pk.shape[0] == p.get_pruned_length(L)
+            # kept bitmap of the middle, recovered by matching output rows to input rows
+            rem = L % bs
+            end_mid = L - bs - rem
+            mid_k = k[bs:end_mid]
+            keyed = {}
+            for t in range(mid_k.shape[0]):
+                for h in range(H):
+                    keyed.setdefault(bits(mid_k[t, h]).tobytes(), []).append((t, h))
+            kept = np.zeros((mid_k.shape[0], H), dtype=np.uint8)
+            out_mid = pk[bs:pk.shape[0] - bs - rem].reshape(-1, D)
+            for r in range(out_mid.shape[0]):
+                t, h = keyed[bits(out_mid[r]).tobytes()].pop(0)
+                kept[t, h] = 1
+            out[f"c{case}_meta"] = np.array([L, budget, bs, H, D, ["global", "local", "inverse_key_l2"].index(method),
+                                             {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}[dtype], 5000 + case])
+            out[f"c{case}_kept"] = np.packbits(kept, axis=0)
+            out[f"c{case}_sha_k"] = np.frombuffer(hashlib.sha256(bits(pk).tobytes()).digest(), dtype=np.uint8)
+            out[f"c{case}_sha_v"] = np.frombuffer(hashlib.sha256(bits(pv).tobytes()).digest(), dtype=np.uint8)
+            case += 1
+    np.savez_compressed(os.path.join(HERE, "prompt_prune_topk_full.npz"), **out)
+
     # ---- (iii) block scores ---------------------------------------------------------
     out = {}
     case = 0

@@ -497,6 +497,31 @@ def test_prompt_token_select_golden(ops, oracle):
         assert torch.equal(pk.cpu(), ek) and torch.equal(pv.cpu(), ev), c
 
 
+def test_prompt_token_select_full_size_golden(ops, oracle):
+    """The reference's prune at the benchmark's prompt sizes (fixtures hold digests and kept
+    bitmaps): exact for tie-free f32 inputs, same kept scores for 16-bit inputs."""
+    from test_oracle_golden import _full_cases, _same_kept_scores, _sha
+    for c, L, budget, bs, H, D, method, dtype, k, v, ref_kept, sha_k, sha_v in _full_cases():
+        n_kept = oracle.pruned_length(L, budget, bs)
+        cu_q, cu_k = _cu([L]).cuda(), _cu([n_kept]).cuda()
+        kd, vd = k.cuda(), v.cuda()
+        if dtype == torch.float32:
+            idx = ops.prompt_token_select(kd, vd, cu_q, cu_k, n_kept, budget, bs, method, compat_q2=True)
+            pk, pv = ops.prompt_prune_gather(kd, vd, idx, mode=2)
+            assert _sha(pk.cpu()) == sha_k and _sha(pv.cpu()) == sha_v, c
+        idx = ops.prompt_token_select(kd, vd, cu_q, cu_k, n_kept, budget, bs, method).cpu().long()
+        end_first, end_mid, n_prune = oracle.prompt_slices(L, budget, bs)
+        mid = idx[end_first:n_kept - (L - end_mid)] - end_first          # kept middle rows per head
+        mine = torch.zeros(end_mid - end_first, H, dtype=torch.bool)
+        mine.scatter_(0, mid, True)
+        assert (mid[1:] > mid[:-1]).all()                                # order preserved per head
+        scores = oracle.token_scores(k[end_first:end_mid], v[end_first:end_mid], method)
+        if dtype == torch.float32:
+            assert torch.equal(mine, ref_kept), c
+        else:
+            _same_kept_scores(scores, mine, ref_kept)
+
+
 @pytest.mark.parametrize("method", ["global", "inverse_key_l2"])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_prompt_token_select_batch_with_ties(ops, oracle, method, dtype):

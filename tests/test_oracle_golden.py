@@ -56,6 +56,57 @@ def test_prompt_prune_topk_golden(oracle):
                                k[bs:L - bs - L % bs][keep[:, h], h])
 
 
+def _full_cases():
+    """Cases of tests/golden/prompt_prune_topk_full.npz: inputs regenerated from their seed."""
+    z = np.load(os.path.join(GOLDEN, "prompt_prune_topk_full.npz"))
+    n = len([k for k in z.files if k.endswith("_meta")])
+    assert n == 10
+    for c in range(n):
+        L, budget, bs, H, D, m, dt, seed = [int(v) for v in z[f"c{c}_meta"]]
+        dtype = {0: torch.float32, 1: torch.float16, 2: torch.bfloat16}[dt]
+        g = torch.Generator().manual_seed(seed)
+        k = (torch.rand(L, H, D, generator=g) * 2 - 1).to(dtype)
+        v = (torch.rand(L, H, D, generator=g) * 2 - 1).to(dtype)
+        n_mid = L - 2 * bs - L % bs
+        kept = np.unpackbits(z[f"c{c}_kept"], axis=0)[:n_mid].astype(bool)
+        yield (c, L, budget, bs, H, D, ["global", "local", "inverse_key_l2"][m], dtype, k, v,
+               torch.from_numpy(kept), bytes(z[f"c{c}_sha_k"]), bytes(z[f"c{c}_sha_v"]))
+
+
+def _sha(t):
+    import hashlib
+    raw = t.contiguous().view(torch.int16) if t.dtype in (torch.bfloat16, torch.float16) else t.contiguous()
+    return hashlib.sha256(raw.numpy().tobytes()).digest()
+
+
+def _same_kept_scores(scores, mine, ref):
+    """Two keep-masks [T, H] select, head by head, the same multiset of scores, and the same tokens
+    wherever a token's score is not shared with another token of that head."""
+    for h in range(scores.shape[1]):
+        s = scores[:, h].float()
+        assert torch.equal(torch.sort(s[mine[:, h]]).values, torch.sort(s[ref[:, h]]).values), h
+        _, inv, cnt = torch.unique(s, return_inverse=True, return_counts=True)
+        unique_tok = cnt[inv] == 1
+        assert torch.equal(mine[unique_tok, h], ref[unique_tok, h]), h
+
+
+def test_prompt_prune_topk_full_size_golden(oracle):
+    """KVCachePruner.prune_prompt at [1024..1030, 8, 128] / [.., 12, 64]: tie-free f32 inputs
+    reproduce the reference's output bytes (SHA-256) and kept bitmap; 16-bit inputs, where
+    torch.topk's pick among tied scores is unspecified, keep the same scores."""
+    for c, L, budget, bs, H, D, method, dtype, k, v, ref_kept, sha_k, sha_v in _full_cases():
+        end_first, end_mid, n_prune = oracle.prompt_slices(L, budget, bs)
+        scores = oracle.token_scores(k[end_first:end_mid], v[end_first:end_mid], method)
+        mine = oracle.topk_keep_mask(scores, n_prune)
+        assert int(mine.sum()) == int(ref_kept.sum()) == (end_mid - end_first - n_prune) * H
+        if dtype == torch.float32:
+            assert torch.equal(mine, ref_kept), c
+            pk, pv = oracle.prompt_prune(k, v, method, budget, bs, compat_q2=True)
+            assert _sha(pk) == sha_k and _sha(pv) == sha_v, c
+        else:
+            _same_kept_scores(scores, mine, ref_kept)
+
+
 def test_block_score_golden(oracle):
     z = np.load(os.path.join(GOLDEN, "block_scores.npz"))
     n = len([k for k in z.files if k.endswith("_meta")])
