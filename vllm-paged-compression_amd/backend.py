@@ -659,6 +659,12 @@ class PagedEvictImpl(_ImplBase):
             self._pending_rmv, self._pending_reqs = dec["rmv"], dec.get("req_ids")
             self._pending_readback = dec.get("readback")
             self.reqids_mapping_rmv_blockIdx = dec["host_rmv"] or {}
+        # the decode kernels take a maximum length only to size their split-KV work: give them
+        # the longest PHYSICAL length (the reference passes the logical one, :446-447, which
+        # over-states what is read once blocks have been evicted)
+        max_len = dm.max_decode_seq_len
+        if self.enabled_paged_eviction and dm.seq_kv_lens:
+            max_len = max(dm.seq_kv_lens)
         # every layer of the step launches with the same metadata: validate once (first layer of
         # the step), then reuse the argument list
         step = meta._pe_step
@@ -668,8 +674,7 @@ class PagedEvictImpl(_ImplBase):
             try:
                 launcher = ops.DecodeLayerLauncher(q, k, v, kv_cache, self.num_heads, self.num_kv_heads,
                                                    self.head_size, dm.slot_mapping, zero_slots,
-                                                   block_tables, seq_lens_arg, dm.max_decode_seq_len,
-                                                   self.scale)
+                                                   block_tables, seq_lens_arg, max_len, self.scale)
                 launcher.tables, launcher.zero = block_tables, zero_slots
             except RuntimeError:
                 launcher = None  # shape outside the launcher's contract: per-op path below
@@ -681,7 +686,7 @@ class PagedEvictImpl(_ImplBase):
         PagedAttention.write_to_paged_cache(k, v, key_cache, value_cache, dm.slot_mapping,
                                             self.kv_cache_dtype, 1.0, 1.0, zero_slots=zero_slots)
         PagedAttention.forward_decode(q, key_cache, value_cache, block_tables, seq_lens_arg,
-                                      dm.max_decode_seq_len, self.kv_cache_dtype, self.num_kv_heads,
+                                      max_len, self.kv_cache_dtype, self.num_kv_heads,
                                       self.scale, None, 1.0, 1.0, output=out[n0:])
 
     def _decode_decision(self, meta, dm, value_cache) -> Dict[str, Any]:

@@ -416,18 +416,27 @@ static int env_int(const char* name, int dflt) {
   return v ? atoi(v) : dflt;
 }
 
-// number of KV splits: enough workgroups to cover the chip a few times, but at least two
-// block pairs per wave per split
+// Number of KV splits.  A split costs a second (merge) launch and a round trip of the partial
+// results, about 3 us, so it only pays when the workgroups are few AND long: measured on MI355X
+// (4 query heads per KV head, head 128) one split is best for every batch at kv 776, while 8
+// workgroups of kv 4104 run 2.7x faster with 8 splits and one 16k-token sequence 6x faster with
+// 16.  Rule: aim at one workgroup per CU, keep at least 24 block pairs (768 tokens) per split,
+// at most 16 splits.
 static int choose_splits(int num_seqs, int num_kv_heads, int max_seq_len) {
   const int forced = env_int("PE_DECODE_SPLITS", 0);
   const int n_pairs = (max_seq_len + 31) / 32;
-  int max_splits = n_pairs / (2 * DEC_WAVES);
+  if (forced > 0) {
+    int max_splits = n_pairs / (2 * DEC_WAVES);
+    if (max_splits < 1) max_splits = 1;
+    if (max_splits > 64) max_splits = 64;
+    return forced < max_splits ? forced : max_splits;
+  }
+  int max_splits = n_pairs / 24;
   if (max_splits < 1) max_splits = 1;
-  if (max_splits > 64) max_splits = 64;
-  if (forced > 0) return forced < max_splits ? forced : max_splits;
+  if (max_splits > 16) max_splits = 16;
   const int64_t wgs = (int64_t)num_seqs * num_kv_heads;
-  const int64_t target = 512;  // two workgroups (8 waves) per CU
-  int splits = (int)((target + wgs - 1) / wgs);
+  const int64_t target = 256;  // one workgroup per CU
+  int splits = (int)(target / wgs);
   if (splits < 1) splits = 1;
   if (splits > max_splits) splits = max_splits;
   return splits;
