@@ -13,7 +13,8 @@ Default workload (BASELINE.json configs[1]): Llama-3-8B attention geometry (32 q
 prompt prune, value_l2 ("global") block eviction at decode.
 
   python bench.py --gpus 1 --steps 3 --warmup 1
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N   (tensor parallel)
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N   (tensor parallel:
+      heads sharded over the ranks, N x 64 requests - weak scaling)
 
 Prints one JSON line on rank 0.
 """
@@ -56,10 +57,14 @@ def parse():
     ap.add_argument("--head-size", type=int, default=128)
     ap.add_argument("--block-size", type=int, default=16)
     ap.add_argument("--prefill-batch", type=int, default=8, help="prompts per prefill step")
-    ap.add_argument("--mode", choices=["tp", "dp"], default="tp",
-                    help="N>1: tp = heads sharded over ranks (strong scaling); dp = replicas (weak)")
-    ap.add_argument("--no-oproj-allreduce", action="store_true",
-                    help="tp: skip the all-reduce of the [tokens, hidden] o_proj output after each layer")
+    ap.add_argument("--mode", choices=["tp", "tp-strong", "dp"], default="tp",
+                    help="N>1: tp = heads sharded over the ranks, requests and prefill batch scaled by N "
+                         "so that every rank streams as many KV bytes as the single GPU does (weak "
+                         "scaling); tp-strong = heads sharded, the same 64 requests; dp = replicas")
+    ap.add_argument("--oproj-allreduce", action="store_true",
+                    help="tp: also all-reduce a [tokens, hidden] tensor after every layer, the exchange "
+                         "of the row-parallel o_proj that follows attention in the model (that GEMM is "
+                         "outside the path and not run, so its reduction is off by default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--alt-evict", type=float, default=0.5,
                     help="second eviction fraction measured after the timed region and reported under "
@@ -115,7 +120,7 @@ class Workload:
         self.qd, self.kd, self.vd = rnd(B, self.Hq), rnd(B, self.Hkv), rnd(B, self.Hkv)
         self.o_partial_p = torch.zeros(Tp, self.hidden, dtype=torch.bfloat16, device=dev)
         self.o_partial_d = torch.zeros(B, self.hidden, dtype=torch.bfloat16, device=dev)
-        self.allreduce = tp_size > 1 and not a.no_oproj_allreduce
+        self.allreduce = tp_size > 1 and a.oproj_allreduce
         # decode-kernel timing (HIP events on the launch stream) of one layer
         self.timed = []          # (start_event, end_event, algorithmic_bytes)
         self.timing_on = False
@@ -296,7 +301,11 @@ def main():
         else:
             dist.init_process_group(backend)
     n_gpus = world
-    tp = a.mode == "tp" and world > 1
+    tp = a.mode in ("tp", "tp-strong") and world > 1
+    if tp and a.mode == "tp":
+        # weak scaling under tensor parallelism: N times the requests over 1/N of the heads
+        a.num_prompts *= world
+        a.prefill_batch *= world
     import vllm_paged_compression_amd as pkg
     pkg.load_library()
     wl = Workload(a, dev, world if tp else 1, rank if tp else 0, dist.group.WORLD if tp else None)
@@ -360,7 +369,8 @@ def main():
         "value": round(value, 2), "unit": "output tok/s (attention hot path)",
         "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
-        "scaling": "strong" if tp else "weak", "vs_baseline": None, "dtype": "bf16",
+        "scaling": "strong" if a.mode == "tp-strong" and world > 1 else "weak", "vs_baseline": None,
+        "dtype": "bf16",
         "data": "synthetic",
         "config": {
             "workload": workload_name(a, wl),

@@ -70,12 +70,24 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void prefill_mfma_kernel(
   auto v_tile = [&](int buf) { return smem + buf * 2 * TILE_BYTES + TILE_BYTES; };
 
   // grid (head, request, query tile): workgroups are dispatched x-fastest, so every request's
-  // heaviest (last) query tiles start first and the short ones fill the tail; consecutive
-  // workgroup ids go to consecutive XCDs, so x enumerates kv heads fastest - the query heads of
-  // one kv head (which read the same K/V) share an XCD's L2 when num_kv_heads % 8 == 0
-  const int seq = blockIdx.y;
-  const int kvh = (int)blockIdx.x % num_kv_heads;
-  const int head = kvh * (num_heads / num_kv_heads) + (int)blockIdx.x / num_kv_heads;
+  // heaviest (last) query tiles start first and the short ones fill the tail.  Consecutive
+  // workgroup ids go to consecutive XCDs; the (head, request) plane is re-enumerated so that all
+  // query heads of one (request, KV head) - which read the same K/V - get ids that are equal
+  // modulo 8 and share one XCD's L2 (needs num_kv_heads * num_requests to be a multiple of 8).
+  const int gqa = num_heads / num_kv_heads;
+  const int lid = (int)blockIdx.x + (int)gridDim.x * (int)blockIdx.y;
+  const int n_groups = num_kv_heads * (int)gridDim.y;
+  int grp, hg;
+  if (n_groups % 8 == 0) {
+    grp = (lid / (8 * gqa)) * 8 + lid % 8;
+    hg = (lid / 8) % gqa;
+  } else {
+    grp = lid / gqa;
+    hg = lid % gqa;
+  }
+  const int seq = grp / num_kv_heads;
+  const int kvh = grp % num_kv_heads;
+  const int head = kvh * gqa + hg;
   const int q0 = cu_q[seq], lq = cu_q[seq + 1] - q0;
   const int kv0 = cu_kv[seq], lkv = cu_kv[seq + 1] - kv0;
   const int qt = (int)gridDim.z - 1 - (int)blockIdx.z;
