@@ -65,6 +65,9 @@ def parse():
                     help="tp: also all-reduce a [tokens, hidden] tensor after every layer, the exchange "
                          "of the row-parallel o_proj that follows attention in the model (that GEMM is "
                          "outside the path and not run, so its reduction is off by default)")
+    ap.add_argument("--per-request-scheduler", action="store_true",
+                    help="drive the decode steps through the per-request scheduler / metadata builder "
+                         "(the reference's shape of the host code) instead of the vectorised ones")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--alt-evict", type=float, default=0.5,
                     help="second eviction fraction measured after the timed region and reported under "
@@ -127,11 +130,14 @@ class Workload:
         self.kv_blocks_peak = 0
 
     # ---- metadata -------------------------------------------------------------------------
-    def _build(self, inter, seq_lens, q_lens):
+    def _builder(self, inter):
         runner = SimpleNamespace(device=self.dev, cache_config=self.ccfg, pin_memory=False)
         ib = SimpleNamespace(runner=runner, sliding_window=None, block_size=self.bs,
                              chunked_prefill_enabled=False, inter_data_list=inter)
-        return self.backend.make_metadata_builder(ib).build(seq_lens, q_lens, -1, len(seq_lens))
+        return self.backend.make_metadata_builder(ib)
+
+    def _build(self, inter, seq_lens, q_lens):
+        return self._builder(inter).build(seq_lens, q_lens, -1, len(seq_lens))
 
     def _layers(self, q, k, v, meta, o_partial, decode_bytes=None):
         """All layers of one step.  For decode steps of the timed region, layers 1..L-1 (layer 0
@@ -155,6 +161,49 @@ class Workload:
 
     # ---- one generation ---------------------------------------------------------------------
     def generate(self):
+        if self.a.per_request_scheduler:
+            return self._generate_per_request()
+        import numpy as np
+        from vllm_paged_compression_amd.batch_scheduler import BatchEvictionScheduler
+        a, bs = self.a, self.bs
+        B, L0 = a.num_prompts, a.input_len
+        sched = BatchEvictionScheduler(bs, self.num_blocks, self.cfg, max_seqs=B,
+                                       max_blocks_per_seq=self.blocks_per_seq_full + 2)
+        rids = [f"req{i}" for i in range(B)]
+        for i, r in enumerate(rids):
+            sched.add_request(r, i, L0)
+        # prefill, --prefill-batch prompts at a time
+        for p0 in range(0, B, a.prefill_batch):
+            grp = list(range(p0, min(B, p0 + a.prefill_batch)))
+            inter = [SimpleNamespace(request_id=rids[i], is_prompt=True,
+                                     block_tables={i: sched.get_block_table(rids[i])},
+                                     seq_kv_lens={i: sched.get_seq_kv_len(rids[i])}, seq_ids=[i],
+                                     input_tokens=[range(L0)], orig_seq_lens=[L0], seq_lens=[L0],
+                                     query_lens=[L0], context_lens=[0]) for i in grp]
+            meta = self._build(inter, [L0] * len(grp), [L0] * len(grp))
+            T = len(grp) * L0
+            self._layers(self.qp[:T], self.kp[:T], self.vp[:T], meta, self.o_partial_p[:T])
+        # decode: one vectorised scheduler step + one metadata build per step
+        L = L0
+        es = 2
+        for _ in range(a.output_len):
+            batch = sched.schedule_decode(rids)
+            L += 1
+            trig = self.cfg is not None and self.cfg.evict_method != "inverse_key_l2" \
+                and L > self.budget and L % bs == 0
+            kv_adj = batch.kv_lens - (bs if trig else 0)     # model_runner.py:538-543
+            meta = self._builder([]).build_decode_batch(batch, kv_adj)
+            nbytes = int((2 * kv_adj * self.Hkv * self.D * es + -(-kv_adj // bs) * 4).sum()) \
+                + 2 * B * self.Hq * self.D * es
+            self._layers(self.qd, self.kd, self.vd, meta, self.o_partial_d, decode_bytes=nbytes)
+            if self.cfg is not None:
+                sched.commit(self.impls[0].get_rmv_block_idx())
+            used = self.num_blocks - sched.get_num_free_gpu_blocks()
+            self.kv_blocks_peak = max(self.kv_blocks_peak, used)
+        for r in rids:
+            sched.finish_request(r)
+
+    def _generate_per_request(self):
         from vllm_paged_compression_amd.block_table import EvictBlockSpaceManager, EvictionScheduler
         a, bs = self.a, self.bs
         B, L0 = a.num_prompts, a.input_len
@@ -318,6 +367,11 @@ def main():
     for _ in range(a.warmup):
         wl.generate()
     sync()
+    # everything allocated so far (library, caches, launch tables) is long-lived: take it out of
+    # the collector's sight so that a full collection (tens of ms) cannot land in a generation
+    import gc
+    gc.collect()
+    gc.freeze()
     wl.timing_on = True
     t0 = time.perf_counter()
     for _ in range(a.steps):

@@ -197,3 +197,95 @@ def test_random_victim_stream(oracle):
         layers = [[rng.randint(1, 10), rng.randint(1, 46)] for _ in range(4)]
         exp.append(layers[0])
     assert got == exp
+
+
+def test_batch_scheduler_matches_per_request_scheduler():
+    """The vectorised scheduler (struct of arrays, one numpy step per decode step) walks the same
+    states as the per-request one: block tables, physical/logical lengths, free-block counts,
+    through allocation, appends across block boundaries, evictions at any index (including the
+    last block) and request turnover; and build_decode_batch yields the metadata build() yields."""
+    import random
+    from types import SimpleNamespace
+    import numpy as np
+    from vllm_paged_compression_amd.backend import PagedEvictBackend
+    from vllm_paged_compression_amd.batch_scheduler import BatchEvictionScheduler
+    from vllm_paged_compression_amd.block_table import EvictBlockSpaceManager, EvictionScheduler
+    from vllm_paged_compression_amd.config import CacheConfigView, PagedEvictConfig
+    bs, nb, budget = 16, 400, 64
+    cfg = PagedEvictConfig(True, "budget", "global", budget, 3)
+    ref = EvictionScheduler(EvictBlockSpaceManager(bs, nb, cfg, watermark=0.0))
+    vec = BatchEvictionScheduler(bs, nb, cfg, max_seqs=8, max_blocks_per_seq=32)
+    rng = random.Random(3)
+    prompts = {"a": 70, "b": 64, "c": 200, "d": 17, "e": 100}
+    seq_of = {r: i for i, r in enumerate(prompts)}
+    for r, n in prompts.items():
+        ref.add_request(r, seq_of[r], n)
+        vec.add_request(r, seq_of[r], n)
+    running = list(prompts)
+    ccfg = CacheConfigView(bs, cfg)
+
+    def builder(inter):
+        runner = SimpleNamespace(device=torch.device("cpu"), cache_config=ccfg, pin_memory=False)
+        ib = SimpleNamespace(runner=runner, sliding_window=None, block_size=bs,
+                             chunked_prefill_enabled=False, inter_data_list=inter)
+        return PagedEvictBackend.make_metadata_builder(ib)
+
+    logical = dict(prompts)
+    for step in range(90):
+        tables, kv_lens = ref.schedule_decode(running)
+        batch = vec.schedule_decode(running)
+        assert vec.get_num_free_gpu_blocks() == ref.block_manager.get_num_free_gpu_blocks()
+        for i, r in enumerate(running):
+            logical[r] += 1
+            sid = seq_of[r]
+            assert batch.block_tables[i, :batch.table_lens[i]].tolist() == tables[sid], (step, r)
+            assert not batch.block_tables[i, batch.table_lens[i]:].any()
+            assert int(batch.kv_lens[i]) == kv_lens[sid] and int(batch.seq_lens[i]) == logical[r]
+        # metadata equality (per-request build vs batched build)
+        inter = [SimpleNamespace(request_id=r, is_prompt=False, block_tables={seq_of[r]: tables[seq_of[r]]},
+                                 seq_kv_lens={seq_of[r]: kv_lens[seq_of[r]]}, seq_ids=[seq_of[r]],
+                                 input_tokens=[[0]], orig_seq_lens=[logical[r]], seq_lens=[logical[r]],
+                                 query_lens=[1], context_lens=[kv_lens[seq_of[r]] - 1]) for r in running]
+        m1 = builder(inter).build([logical[r] for r in running], [1] * len(running), -1, len(running))
+        m2 = builder([]).build_decode_batch(batch, batch.kv_lens)
+        for f in ("slot_mapping", "seq_lens_tensor", "query_start_loc", "seq_start_loc",
+                  "context_lens_tensor", "block_tables", "seq_kv_lens_tensor"):
+            assert torch.equal(getattr(m1, f), getattr(m2, f)), (step, f)
+        assert m1.seq_lens == m2.seq_lens and m1.seq_kv_lens == m2.seq_kv_lens
+        assert (m1.max_decode_seq_len, m1.num_decode_tokens) == (m2.max_decode_seq_len, m2.num_decode_tokens)
+        # evict somewhere in some sequences (any index >= 1, the last block included)
+        rmv = {}
+        for i, r in enumerate(running):
+            n = int(batch.table_lens[i])
+            if n > 3 and rng.random() < 0.3:
+                rmv[i] = (r, rng.randint(1, n - 1))
+        ref.commit(rmv)
+        vec.commit(rmv)
+        for r in running:
+            assert vec.get_block_table(r) == ref.block_manager.get_block_table(seq_of[r])
+            assert vec.get_seq_kv_len(r) == ref.block_manager.get_seq_kv_len(seq_of[r])
+        if step == 40:      # turnover: one request leaves, a new one arrives
+            ref.finish_request("b")
+            vec.finish_request("b")
+            running.remove("b")
+            ref.add_request("f", 9, 130)
+            vec.add_request("f", 9, 130)
+            seq_of["f"], logical["f"] = 9, 130
+            running.append("f")
+    for r in running:
+        ref.finish_request(r)
+        vec.finish_request(r)
+    assert vec.get_num_free_gpu_blocks() == nb == ref.block_manager.get_num_free_gpu_blocks()
+
+
+def test_launcher_signature_is_view_invariant():
+    """The per-step decode launcher is built from [T, H, D] views and matched against the
+    [T, H*D] tensors the next layers pass: both must give the same signature."""
+    from vllm_paged_compression_amd.ops import DecodeLayerLauncher
+    q = torch.zeros(5, 4 * 16)
+    k = torch.zeros(5, 2 * 16)
+    kv = torch.zeros(2, 7, 16 * 2 * 16)
+    a = DecodeLayerLauncher.signature(q, k, k, kv)
+    b = DecodeLayerLauncher.signature(q.view(5, 4, 16), k.view(5, 2, 16), k.view(5, 2, 16), kv)
+    assert a == b
+    assert a != DecodeLayerLauncher.signature(q[:4], k[:4], k[:4], kv)

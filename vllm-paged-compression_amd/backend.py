@@ -142,6 +142,8 @@ class PagedEvictMetadata(_MetadataBase):
         self.attn_bias = None
         # per-step scratch shared by all layers (decision, kept-row index, prefix sums)
         self._pe_step: Dict[str, Any] = {}
+        # set by build_decode_batch: the step's DecodeBatch (request ids, table lengths as arrays)
+        self._pe_batch = None
 
     def asdict_zerocopy(self, skip_fields=None) -> Dict[str, Any]:
         skip = skip_fields or set()
@@ -335,6 +337,37 @@ class PagedEvictMetadataBuilder(_BuilderBase):
             reqid_mapping_blocktables=self.reqid_mapping_blocktables)
 
 
+    def build_decode_batch(self, batch, seq_kv_lens) -> PagedEvictMetadata:
+        """Metadata of a pure decode step straight from a ``batch_scheduler.DecodeBatch`` - the
+        same fields ``build`` derives sequence by sequence, computed with array operations.
+        ``seq_kv_lens``: the physical lengths attention reads (``batch.kv_lens``, minus a block
+        on the steps that evict, as the model runner adjusts them, model_runner.py:538-543)."""
+        bs = self.block_size
+        B = len(batch.request_ids)
+        device = self.runner.device
+        i32 = np.int32
+        kv = np.asarray(seq_kv_lens, dtype=np.int64)
+        ctx = batch.kv_lens - 1
+        last = batch.block_tables[np.arange(B), batch.table_lens - 1].astype(np.int64)
+        slots = last * bs + ctx % bs                      # torch_cuda_sdpa.py:590-597
+        seq_lens = batch.seq_lens
+        (slot_mapping_t, seq_lens_t, query_start_t, seq_start_t, context_lens_t, bt,
+         seq_kv_lens_t) = staging.upload([
+             slots, seq_lens.astype(i32), np.arange(B + 1, dtype=i32),
+             np.concatenate(([0], np.cumsum(seq_lens))).astype(i32), ctx.astype(i32),
+             np.ascontiguousarray(batch.block_tables, dtype=i32), kv.astype(i32)], device)
+        meta = PagedEvictMetadata(
+            num_prefills=0, slot_mapping=slot_mapping_t, multi_modal_placeholder_index_maps=None,
+            num_prefill_tokens=0, num_decode_tokens=B, seq_lens=seq_lens.tolist(),
+            seq_lens_tensor=seq_lens_t, max_query_len=1, max_prefill_seq_len=0,
+            max_decode_seq_len=int(seq_lens.max()) if B else 0, query_start_loc=query_start_t,
+            seq_start_loc=seq_start_t, context_lens_tensor=context_lens_t, block_tables=bt,
+            use_cuda_graph=False, seq_kv_lens=kv.tolist(), seq_kv_lens_tensor=seq_kv_lens_t,
+            reqid_mapping_blocktables=None)
+        meta._pe_batch = batch
+        return meta
+
+
 # ------------------------------------------------------------------------------------------
 class DeviceScoreTable:
     """Block scores of the running sequences, resident on the GPU: f32 [rows, width] plus a
@@ -498,7 +531,8 @@ class PagedEvictImpl(_ImplBase):
                 self.compat.per_layer_decision or self.layer_idx <= 0
                 or "mgr" not in attn_metadata._pe_step):
             # only the deciding layer tracks the batch composition
-            self.block_l2norm_mgr.update_reqs(attn_metadata.reqid_mapping_blocktables)
+            if attn_metadata.reqid_mapping_blocktables is not None:
+                self.block_l2norm_mgr.update_reqs(attn_metadata.reqid_mapping_blocktables)
             attn_metadata._pe_step.setdefault("mgr", self.block_l2norm_mgr)
 
         if (pm := attn_metadata.prefill_metadata) is not None:
@@ -700,19 +734,32 @@ class PagedEvictImpl(_ImplBase):
         method = cfg.evict_method
         seq_lens = dm.seq_lens
         dev = dm.block_tables.device
-        over = [L > cfg.cache_budget for L in seq_lens]
-        trig = [o and L % bs == 0 for o, L in zip(over, seq_lens)]
         mgr = step.get("mgr", self.block_l2norm_mgr)
+        batch = getattr(meta, "_pe_batch", None)
+        n_seqs = len(seq_lens)
+        if batch is not None:       # array view of the step (vectorised scheduler)
+            L = batch.seq_lens
+            req_ids = batch.request_ids
+            keys = list(zip(batch.request_ids, batch.seq_ids))
+            table_lens = batch.table_lens.astype(np.int64)
+        else:                       # per-request mapping of the reference's builder
+            L = np.asarray(seq_lens, dtype=np.int64)
+            keys = [mgr.get_reqid_and_seqid(i) for i in range(n_seqs)]
+            req_ids = [k[0] for k in keys]
+            table_lens = np.fromiter((len(mgr.get_req_block_tables(i)) for i in range(n_seqs)),
+                                     dtype=np.int64, count=n_seqs)
+        over_np = L > cfg.cache_budget
+        trig_np = over_np & (L % bs == 0)
+        over, trig = over_np.tolist(), trig_np.tolist()
+        any_trig = bool(trig_np.any())
         dec: Dict[str, Any] = {"rmv": None, "tables": None, "zero_slots": None, "host_rmv": None,
-                               "req_ids": [mgr.get_reqid_and_seqid(i)[0] for i in range(len(seq_lens))]
-                               if any(trig) else None}
+                               "req_ids": req_ids if any_trig else None}
         # width of the compacted table: the longest row once the victims are gone (the
         # reference always uses M-1 and so can cut a full-length row that evicts nothing)
         M = dm.block_tables.shape[1]
         width = M - 1
-        if not self.compat.block_table_slice_in_loop and any(trig):
-            width = max(len(mgr.get_req_block_tables(i)) - (1 if t else 0)
-                        for i, t in enumerate(trig))
+        if not self.compat.block_table_slice_in_loop and any_trig:
+            width = int((table_lens - trig_np).max())
             width = min(max(width, 1), M)
         if method == "inverse_key_l2":
             # zero one random middle slot per over-budget sequence (torch_cuda_sdpa.py:1435-1475)
@@ -720,24 +767,23 @@ class PagedEvictImpl(_ImplBase):
             for i, o in enumerate(over):
                 if not o:
                     continue
-                ids = mgr.get_req_block_tables(i)
+                ids = (batch.block_tables[i, :table_lens[i]].tolist() if batch is not None
+                       else mgr.get_req_block_tables(i))
                 slots.append(ids[random.randint(1, len(ids) - 2)] * bs + random.randint(0, bs - 1))
             if slots:
                 dec["zero_slots"] = staging.upload([np.asarray(slots, dtype=np.int64)], dev)[0]
         elif method in ("streamingLLM", "streamingLLM-1"):
-            need_zero = method == "streamingLLM-1" and any(o and not t for o, t in zip(over, trig))
-            if any(trig) or need_zero:
+            need_zero = method == "streamingLLM-1" and bool((over_np & ~trig_np).any())
+            if any_trig or need_zero:
                 rmv, tables, zero = ops.evict_select_compact(
                     dm.block_tables, dm.seq_lens_tensor, dm.seq_lens_tensor, method,
                     cfg.cache_budget, bs, compat_q1=self.compat.block_table_slice_in_loop,
-                    compact=any(trig), out_width=width)
-                dec["tables"] = tables if any(trig) else None
+                    compact=any_trig, out_width=width)
+                dec["tables"] = tables if any_trig else None
                 dec["zero_slots"] = zero
-                dec["host_rmv"] = {i: (mgr.get_reqid_and_seqid(i)[0], 1)
-                                   for i, t in enumerate(trig) if t}
-        elif any(trig):
-            nblk = staging.upload_i32([len(mgr.get_req_block_tables(i))
-                                       for i in range(len(seq_lens))], dev)
+                dec["host_rmv"] = {i: (req_ids[i], 1) for i, t in enumerate(trig) if t}
+        elif any_trig:
+            nblk = staging.upload_i32(table_lens, dev)
             override = None
             if self.compat.random_victim:
                 ov = []
@@ -745,7 +791,7 @@ class PagedEvictImpl(_ImplBase):
                     if not t:
                         ov.append(-1)
                         continue
-                    n = len(mgr.get_req_block_tables(i))
+                    n = int(table_lens[i])
                     end = 1 + cfg.topk_blocks if method == "local" else n - 1
                     ov.append(random.randint(1, end - 1))
                 override = staging.upload_i32(ov, dev)
@@ -753,8 +799,7 @@ class PagedEvictImpl(_ImplBase):
                     dm.block_tables, dm.seq_lens_tensor, nblk, method, cfg.cache_budget, bs,
                     cfg.topk_blocks, victim_override=override,
                     compat_q1=self.compat.block_table_slice_in_loop, out_width=width)
-                dec["host_rmv"] = {i: (mgr.get_reqid_and_seqid(i)[0], r)
-                                   for i, r in enumerate(ov) if r >= 0}
+                dec["host_rmv"] = {i: (req_ids[i], r) for i, r in enumerate(ov) if r >= 0}
             elif self._tp_size() > 1 and not self._tp_exact_scores() \
                     and parallel.group_rank(self.tp_group) != 0:
                 # data-dependent victims are decided by the first rank of the TP group and
@@ -768,9 +813,8 @@ class PagedEvictImpl(_ImplBase):
                 dec["rmv"] = rmv
             else:
                 table = self._table(dev)
-                self._sync_rows(table)
-                rows = staging.upload_i32([table.row_of(mgr.get_reqid_and_seqid(i))
-                                           for i in range(len(seq_lens))], dev)
+                table.retain_only(keys if batch is not None else list(mgr.flat_sequence_map))
+                rows = staging.upload_i32([table.row_of(k) for k in keys], dev)
                 table.flush_new_rows()
                 new_scores = None
                 if self._tp_exact_scores():

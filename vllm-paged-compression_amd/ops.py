@@ -527,8 +527,10 @@ class DecodeLayerLauncher:
 
     @staticmethod
     def signature(query, key, value, kv_cache):
-        return (query.shape, query.stride(0), key.shape, key.stride(0), value.stride(0),
-                kv_cache.shape, kv_cache.dtype, query.dtype, query.device)
+        # rows / elements / row strides: the same for the [T, H*D] tensors a layer receives and
+        # their [T, H, D] views
+        return (query.shape[0], query.numel(), query.stride(0), key.numel(), key.stride(0),
+                value.stride(0), kv_cache.shape, kv_cache.dtype, query.dtype, query.device)
 
     def matches(self, query, key, value, kv_cache) -> bool:
         return self.sig == self.signature(query, key, value, kv_cache)

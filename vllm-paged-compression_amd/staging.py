@@ -21,7 +21,7 @@ _ALIGN = 16
 class PinnedStager:
     """Ring of pinned host buffers; one async H2D copy per ``upload`` call."""
 
-    def __init__(self, depth: int = 8, min_bytes: int = 1 << 16) -> None:
+    def __init__(self, depth: int = 8, min_bytes: int = 1 << 20) -> None:
         self.depth = depth
         self.min_bytes = min_bytes
         self._bufs: List[Optional[torch.Tensor]] = [None] * depth
@@ -45,7 +45,12 @@ class PinnedStager:
             ev.synchronize()  # the copy that last used this buffer; long done in steady state
         buf = self._bufs[i]
         if buf is None or buf.numel() < total:
-            buf = torch.empty(max(total, self.min_bytes), dtype=torch.uint8, pin_memory=True)
+            # pinned allocations cost milliseconds: size generously (power of two) so that the
+            # ring stops growing after the first few steps
+            size = self.min_bytes
+            while size < total:
+                size *= 2
+            buf = torch.empty(size, dtype=torch.uint8, pin_memory=True)
             self._bufs[i] = buf
         hn = buf.numpy()
         for a, off in zip(arrays, offs):
