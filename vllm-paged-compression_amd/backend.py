@@ -604,6 +604,22 @@ class PagedEvictImpl(_ImplBase):
                     if self.enabled_paged_eviction:
                         self._prompt_block_scores(v, list(seq_lens), meta)
 
+    def _step_keys(self, meta) -> List[Tuple[str, int]]:
+        """(request id, sequence id) of every sequence of the step, in batch order."""
+        step = meta._pe_step
+        keys = step.get("keys")
+        if keys is None:
+            batch = getattr(meta, "_pe_batch", None)
+            if batch is not None:
+                keys = list(zip(batch.request_ids, batch.seq_ids))
+            elif self.compat.request_order_first_seen or meta.reqid_mapping_blocktables is None:
+                mgr = step.get("mgr", self.block_l2norm_mgr)
+                keys = list(mgr.flat_sequence_map)
+            else:
+                keys = [(r, s) for r, tables in meta.reqid_mapping_blocktables.items() for s in tables]
+            step["keys"] = keys
+        return keys
+
     def _tp_size(self) -> int:
         return parallel.group_size(self.tp_group) if self.tp_group is not None else 1
 
@@ -638,7 +654,7 @@ class PagedEvictImpl(_ImplBase):
             return
         bs = self.cache_config.block_size
         table = self._table(values.device)
-        self._sync_rows(table)
+        keys = self._step_keys(meta)
         off = 0
         rows, counts = [], []
         exact_tp = self._tp_exact_scores()
@@ -649,7 +665,7 @@ class PagedEvictImpl(_ImplBase):
             so = 0
         for i, n in enumerate(kept):
             nb = n // bs
-            row = table.row_of(self.block_l2norm_mgr.get_reqid_and_seqid(i))
+            row = table.row_of(keys[i])
             if nb > 0:
                 if exact_tp:
                     ops.block_token_norm_sums(values[off:off + nb * bs], None, nb,
@@ -672,9 +688,6 @@ class PagedEvictImpl(_ImplBase):
                                                     out=table.scores[row, :nb])
                     so += nb * bs
         table.set_counts(rows, counts)
-
-    def _sync_rows(self, table: DeviceScoreTable) -> None:
-        table.retain_only(list(self.block_l2norm_mgr.flat_sequence_map))
 
     # ------------------------------------------------------------------------------- decode
     def _forward_decode(self, out, query, key, value, key_cache, value_cache, meta, dm,
@@ -737,17 +750,21 @@ class PagedEvictImpl(_ImplBase):
         mgr = step.get("mgr", self.block_l2norm_mgr)
         batch = getattr(meta, "_pe_batch", None)
         n_seqs = len(seq_lens)
+        keys = self._step_keys(meta)
+        req_ids = [k[0] for k in keys]
         if batch is not None:       # array view of the step (vectorised scheduler)
             L = batch.seq_lens
-            req_ids = batch.request_ids
-            keys = list(zip(batch.request_ids, batch.seq_ids))
             table_lens = batch.table_lens.astype(np.int64)
+            table_of = lambda i: batch.block_tables[i, :table_lens[i]].tolist()  # noqa: E731
         else:                       # per-request mapping of the reference's builder
             L = np.asarray(seq_lens, dtype=np.int64)
-            keys = [mgr.get_reqid_and_seqid(i) for i in range(n_seqs)]
-            req_ids = [k[0] for k in keys]
-            table_lens = np.fromiter((len(mgr.get_req_block_tables(i)) for i in range(n_seqs)),
-                                     dtype=np.int64, count=n_seqs)
+            mapping = meta.reqid_mapping_blocktables
+            table_of = lambda i: mapping[keys[i][0]][keys[i][1]]  # noqa: E731
+            table_lens = np.fromiter((len(table_of(i)) for i in range(n_seqs)), dtype=np.int64,
+                                     count=n_seqs)
+        if self._score_table is not None:
+            # a decode step lists every running sequence: whoever is absent has finished
+            self._score_table.retain_only(keys)
         over_np = L > cfg.cache_budget
         trig_np = over_np & (L % bs == 0)
         over, trig = over_np.tolist(), trig_np.tolist()
@@ -767,8 +784,7 @@ class PagedEvictImpl(_ImplBase):
             for i, o in enumerate(over):
                 if not o:
                     continue
-                ids = (batch.block_tables[i, :table_lens[i]].tolist() if batch is not None
-                       else mgr.get_req_block_tables(i))
+                ids = table_of(i)
                 slots.append(ids[random.randint(1, len(ids) - 2)] * bs + random.randint(0, bs - 1))
             if slots:
                 dec["zero_slots"] = staging.upload([np.asarray(slots, dtype=np.int64)], dev)[0]
@@ -813,7 +829,6 @@ class PagedEvictImpl(_ImplBase):
                 dec["rmv"] = rmv
             else:
                 table = self._table(dev)
-                table.retain_only(keys if batch is not None else list(mgr.flat_sequence_map))
                 rows = staging.upload_i32([table.row_of(k) for k in keys], dev)
                 table.flush_new_rows()
                 new_scores = None

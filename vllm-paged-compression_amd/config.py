@@ -87,10 +87,16 @@ class CompatFlags:
     random_victim: bool = False
     # every layer takes its own decision; only layer 0's is committed (model_runner.py:1797-1802)
     per_layer_decision: bool = False
+    # batch index -> request through BlockL2NormManager's flat map, which lists requests in the
+    # order they were first seen and forgets every request absent from a step - a prefill step
+    # of new prompts drops all running ones (block_l2norm_manager.py:15-61); the default maps
+    # index i to the i-th sequence of the step's own metadata and keeps scores until a request
+    # is absent from a decode step
+    request_order_first_seen: bool = False
 
     @classmethod
     def reference_head(cls) -> "CompatFlags":
-        return cls(True, True, True, True, True, True)
+        return cls(True, True, True, True, True, True, True)
 
 
 @dataclass
