@@ -22,9 +22,10 @@ def _rand(T, H, g, scale):
 
 
 @pytest.mark.parametrize("vectorised", [False, True])
-@pytest.mark.parametrize("method,seed", [("streamingLLM", 0), ("streamingLLM-1", 1), ("global", 2),
-                                         ("global", 3), ("local", 4)])
-def test_continuous_batching_fuzz(oracle, method, seed, vectorised):
+@pytest.mark.parametrize("method,seed,evict_before_prefill", [
+    ("streamingLLM", 0, False), ("streamingLLM-1", 1, False), ("global", 2, False), ("global", 3, False),
+    ("local", 4, False), ("streamingLLM", 5, True), ("global", 6, True)])
+def test_continuous_batching_fuzz(oracle, method, seed, evict_before_prefill, vectorised):
     from vllm_paged_compression_amd.backend import PagedEvictBackend
     from vllm_paged_compression_amd.batch_scheduler import BatchEvictionScheduler
     from vllm_paged_compression_amd.block_table import EvictBlockSpaceManager, EvictionScheduler
@@ -33,7 +34,7 @@ def test_continuous_batching_fuzz(oracle, method, seed, vectorised):
     rng = random.Random(100 + seed)
     g = torch.Generator().manual_seed(200 + seed)
     nb = 160
-    cfg = PagedEvictConfig(True, "budget", method, BUDGET, TOPK)
+    cfg = PagedEvictConfig(not evict_before_prefill, "budget", method, BUDGET, TOPK)
     ccfg = CacheConfigView(BS, cfg)
     impls = [PagedEvictBackend.get_impl_cls()(HQ, D, D ** -0.5, HKV, None, None, "auto", None, None,
                                               cache_config=ccfg, prefix=f"model.layers.{i}.self_attn.attn",
@@ -102,7 +103,11 @@ def test_continuous_batching_fuzz(oracle, method, seed, vectorised):
                     pk.append(a)
                     pv.append(b)
                     off += n
-                ref = oracle.prefill_attention(q3.float(), k3.float(), v3.float(), lens, lens, D ** -0.5)
+                if evict_before_prefill:   # attention over the pruned K/V, top-left causal mask
+                    ref = oracle.prefill_attention(q3.float(), torch.cat(pk).float(), torch.cat(pv).float(),
+                                                   lens, [t.shape[0] for t in pk], D ** -0.5)
+                else:
+                    ref = oracle.prefill_attention(q3.float(), k3.float(), v3.float(), lens, lens, D ** -0.5)
                 torch.testing.assert_close(out.cpu().float().view(T, HQ, D), ref, atol=2e-2, rtol=1.6e-2)
                 oracle.reshape_and_cache(torch.cat(pk), torch.cat(pv), kc_cpu[li], vc_cpu[li],
                                          torch.tensor(slot_expect))
