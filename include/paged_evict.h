@@ -277,6 +277,31 @@ int pe_evict_select_compact(int32_t* rmv_idx_out, int32_t* out_tables,
                             int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Rotary position embedding fused with the KV write - the two launches that precede the
+ * attention path in the model (vllm/model_executor/models/llama.py:202-205):
+ * rotary_embedding (csrc/pos_encoding_kernels.cu:10-35,124-162; schema
+ * csrc/torch_bindings.cpp "rotary_embedding(Tensor positions, Tensor! query, Tensor! key,
+ * int head_size, Tensor cos_sin_cache, bool is_neox)") followed by reshape_and_cache
+ * (csrc/cache_kernels.cu:152-289).
+ *   query [num_tokens, num_heads, head_size] and key [num_tokens, num_kv_heads, head_size]
+ *     (row strides q_stride / k_stride, e.g. views of the fused qkv projection) are rotated
+ *     in place: element pairs (i, i + rot_dim/2) for is_neox != 0, (2i, 2i+1) otherwise,
+ *     with cos = cos_sin_cache[pos][i], sin = cos_sin_cache[pos][rot_dim/2 + i]; the products
+ *     and their sum are each rounded to the storage type, as the reference kernel does.
+ *     Elements past rot_dim pass through.  positions are clamped to [0, max_position).
+ *   With key_cache != NULL the rotated key row and the value row of token t are also written
+ *     to slot slot_mapping[t] (< 0 or out of range: token not cached) in the layouts of
+ *     pe_reshape_and_cache; with key_cache == NULL only the rotation is done.
+ * ---------------------------------------------------------------------------------- */
+int pe_rope_reshape_and_cache(void* query, void* key, const void* value, void* key_cache,
+                              void* value_cache, const int64_t* positions,
+                              const void* cos_sin_cache, const int64_t* slot_mapping,
+                              int64_t num_tokens, int64_t q_stride, int64_t k_stride,
+                              int64_t v_stride, int num_heads, int num_kv_heads, int head_size,
+                              int rot_dim, int is_neox, int64_t max_position, int block_size,
+                              int64_t num_blocks, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Block copy / swap — backend-API obligations (vllm/attention/backends/abstract.py:79-94).
  * pe_copy_blocks replaces torch.ops._C_cache_ops.copy_blocks
  * (csrc/cache_kernels.cu:68-148): cache_ptrs device arrays of num_layers device pointers,

@@ -304,6 +304,36 @@ float orc_block_score(const void* values, int block_size, int num_kv_heads,
 }
 
 /*
+ * Rotary position embedding, csrc/pos_encoding_kernels.cu:10-35 (apply_token_rotary_embedding)
+ * and :38-71 (all heads of query and key of one token).  The reference computes in the storage
+ * type: x*cos, y*sin and their difference / sum are each rounded to it.  rows [num_tokens][heads]
+ * [head_size] with row stride `stride` (elements); cos_sin [max_position][rot_dim].
+ */
+void orc_rotary_embedding(const int64_t* positions, void* rows, const void* cos_sin, int num_tokens,
+                          int num_heads, int head_size, int64_t stride, int rot_dim, int is_neox,
+                          int dtype) {
+  const int embed = rot_dim / 2;
+  for (int t = 0; t < num_tokens; ++t) {
+    const int64_t cbase = positions[t] * rot_dim;
+    for (int h = 0; h < num_heads; ++h) {
+      const int64_t base = (int64_t)t * stride + (int64_t)h * head_size;
+      for (int i = 0; i < embed; ++i) {
+        const int xi = is_neox ? i : 2 * i;
+        const int yi = is_neox ? embed + i : 2 * i + 1;
+        const float c = load_elem(cos_sin, cbase + i, dtype);
+        const float s = load_elem(cos_sin, cbase + embed + i, dtype);
+        const float x = load_elem(rows, base + xi, dtype);
+        const float y = load_elem(rows, base + yi, dtype);
+        volatile float xc = round_to(x * c, dtype), ys = round_to(y * s, dtype);
+        volatile float yc = round_to(y * c, dtype), xs = round_to(x * s, dtype);
+        store_elem(rows, base + xi, xc - ys, dtype);
+        store_elem(rows, base + yi, yc + xs, dtype);
+      }
+    }
+  }
+}
+
+/*
  * The same score split at the head mean, for caches whose KV heads are spread over
  * tensor-parallel ranks (each rank passes its own heads): orc_block_token_norm_sums gives,
  * per token, the f32 sum over the given heads of the rounded norms; the ranks' arrays are

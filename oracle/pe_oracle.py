@@ -128,6 +128,20 @@ def block_score(values: torch.Tensor, block_size: int, num_kv_heads: int, head_s
                                        ctypes.c_int(layout), ctypes.c_int(_DT[values.dtype])))
 
 
+def rotary_embedding(positions: torch.Tensor, rows: torch.Tensor, head_size: int,
+                     cos_sin_cache: torch.Tensor, is_neox: bool) -> torch.Tensor:
+    """Rotated copy of rows [T, heads*head_size] (or [T, heads, head_size])."""
+    T = positions.numel()
+    out = rows.reshape(T, -1).contiguous().clone()
+    cs = cos_sin_cache.contiguous()
+    pos = positions.to(torch.int64).contiguous()
+    lib().orc_rotary_embedding(_p(pos), _p(out), _p(cs), ctypes.c_int(T),
+                               ctypes.c_int(out.shape[1] // head_size), ctypes.c_int(head_size),
+                               ctypes.c_int64(out.shape[1]), ctypes.c_int(cs.shape[1]),
+                               ctypes.c_int(1 if is_neox else 0), ctypes.c_int(_DT[rows.dtype]))
+    return out.view(rows.shape)
+
+
 def block_token_norm_sums(values: torch.Tensor, block_size: int, num_kv_heads: int, head_size: int,
                           layout: int) -> torch.Tensor:
     """Per token of one block, the f32 sum over the given heads of the rounded norms."""

@@ -665,3 +665,51 @@ def test_evict_select_compact_with_caller_scores(oracle):
     assert torch.equal(r1, r2) and torch.equal(o1, o2)
     assert torch.equal(t1, t2) and torch.equal(c1, c2)
     assert (r1.cpu() >= 0).sum() == 3 and r1[2].item() == -1
+
+
+# ------------------------------------------------------------------ rotary embedding + KV write
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("is_neox", [True, False])
+@pytest.mark.parametrize("Hq,Hkv,D,rot", [(32, 8, 128, 128), (12, 12, 64, 64), (8, 2, 128, 64)])
+def test_rope_reshape_and_cache(ops, oracle, dtype, is_neox, Hq, Hkv, D, rot):
+    """Fused rotary embedding + KV write: Q and K rotated in place exactly as the oracle rotates
+    them (storage-type rounding of every product and sum), rotated K and V in the paged cache
+    byte for byte; tokens without a slot are rotated but not cached; q/k/v are views of one fused
+    qkv tensor (strided rows)."""
+    from test_oracle_golden import rope_cache
+    g = torch.Generator().manual_seed(Hq + D + rot + int(is_neox))
+    T, bs, nb, max_pos = 53, 16, 9, 2048
+    cs = rope_cache(max_pos, rot, dtype)
+    pos = torch.randint(0, max_pos, (T,), generator=g)
+    qkv = (torch.rand(T, (Hq + 2 * Hkv) * D, generator=g) * 2 - 1).to(dtype)
+    q, k, v = qkv.split([Hq * D, Hkv * D, Hkv * D], dim=-1)
+    perm = torch.randperm(nb * bs, generator=g)
+    slots = perm[(perm < 32) | (perm >= 48)][:T].to(torch.int64)   # every slot at most once
+    slots[5] = -1
+    slots[20:36] = torch.arange(32, 48)           # an aligned run: the vectorised V store path
+    x = 16 // qkv.element_size()
+    kc, vc = make_cache(nb, Hkv, D, bs, dtype, g)
+    q_ref = oracle.rotary_embedding(pos, q, D, cs, is_neox)
+    k_ref = oracle.rotary_embedding(pos, k, D, cs, is_neox)
+    kc_ref, vc_ref = kc.clone(), vc.clone()
+    oracle.reshape_and_cache(k_ref.reshape(T, Hkv, D), v.reshape(T, Hkv, D).contiguous(), kc_ref, vc_ref, slots)
+    qkv_d = qkv.cuda()
+    qd, kd, vd = qkv_d.split([Hq * D, Hkv * D, Hkv * D], dim=-1)
+    kc_d, vc_d = kc.cuda(), vc.cuda()
+    ops.rotary_embedding_and_cache(pos.cuda(), qd, kd, vd, kc_d, vc_d, slots.cuda(), D, cs.cuda(), is_neox)
+    if dtype == torch.float32:
+        torch.testing.assert_close(qd.cpu(), q_ref, atol=1e-6, rtol=1e-6)
+        torch.testing.assert_close(kd.cpu(), k_ref, atol=1e-6, rtol=1e-6)
+        torch.testing.assert_close(kc_d.cpu(), kc_ref, atol=1e-6, rtol=1e-6)
+    else:
+        assert torch.equal(qd.cpu(), q_ref) and torch.equal(kd.cpu(), k_ref)
+        assert torch.equal(kc_d.cpu(), kc_ref)
+    assert torch.equal(vd.cpu(), v)                 # V untouched
+    assert torch.equal(vc_d.cpu(), vc_ref)
+    # rotation only (the plain rotary_embedding op): same Q/K, no cache involved
+    qkv_d2 = qkv.cuda()
+    q2, k2, _ = qkv_d2.split([Hq * D, Hkv * D, Hkv * D], dim=-1)
+    ops.rotary_embedding(pos.cuda(), q2, k2, D, cs.cuda(), is_neox)
+    assert torch.equal(q2, qd) and torch.equal(k2, kd)
+    # empty batch
+    ops.rotary_embedding(pos[:0].cuda(), q2[:0], k2[:0], D, cs.cuda(), is_neox)

@@ -193,3 +193,48 @@ def test_decode_trace_streaming(oracle):
     assert all(r in (-1, 1) for _, _, _, r in tr)
     tr = oracle.simulate_streaming_generation(1024, 100, 512, 16)
     assert min(k for _, k, _, _ in tr) >= 512 and max(k for _, k, _, _ in tr) <= 528
+
+
+def _native_rope(positions, x, head_size, cos_sin_cache, is_neox):
+    """RotaryEmbedding.forward_native as a torch expression (rotary_embedding.py:45-71,121-149):
+    every operation in the tensors' dtype.  The reference module itself is not importable here
+    (it imports the vllm package), so this pins the oracle against the formula, not against a run
+    of the reference."""
+    T = positions.numel()
+    rot = cos_sin_cache.shape[1]
+    cos, sin = cos_sin_cache.index_select(0, positions).chunk(2, dim=-1)
+    cos, sin = cos.unsqueeze(-2).to(x.dtype), sin.unsqueeze(-2).to(x.dtype)
+    xr = x.view(T, -1, head_size)
+    x_rot, x_pass = xr[..., :rot], xr[..., rot:]
+    if is_neox:
+        x1, x2 = torch.chunk(x_rot, 2, dim=-1)
+    else:
+        x1, x2 = x_rot[..., ::2], x_rot[..., 1::2]
+    o1 = x1 * cos - x2 * sin
+    o2 = x2 * cos + x1 * sin
+    o = torch.cat((o1, o2), dim=-1) if is_neox else torch.stack((o1, o2), dim=-1).flatten(-2)
+    return torch.cat((o, x_pass), dim=-1).reshape(x.shape)
+
+
+def rope_cache(max_pos, rot_dim, dtype, base=10000.0):
+    """cos/sin table as RotaryEmbedding._compute_cos_sin_cache builds it (rotary_embedding.py:96-119)."""
+    inv_freq = 1.0 / (base ** (torch.arange(0, rot_dim, 2, dtype=torch.float) / rot_dim))
+    freqs = torch.einsum("i,j -> ij", torch.arange(max_pos, dtype=torch.float), inv_freq)
+    return torch.cat((freqs.cos(), freqs.sin()), dim=-1).to(dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("is_neox", [True, False])
+@pytest.mark.parametrize("H,D,rot", [(8, 128, 128), (12, 64, 64), (4, 128, 64)])
+def test_rotary_embedding_oracle_matches_native_form(oracle, dtype, is_neox, H, D, rot):
+    g = torch.Generator().manual_seed(H + D + rot)
+    T, max_pos = 37, 4096
+    cs = rope_cache(max_pos, rot, dtype)
+    pos = torch.randint(0, max_pos, (T,), generator=g)
+    x = (torch.rand(T, H * D, generator=g) * 2 - 1).to(dtype)
+    got = oracle.rotary_embedding(pos, x, D, cs, is_neox)
+    want = _native_rope(pos, x, D, cs, is_neox)
+    if dtype == torch.float32:
+        torch.testing.assert_close(got, want, atol=1e-6, rtol=1e-6)   # a*b-c*d: no rounding contract
+    else:
+        assert torch.equal(got, want)

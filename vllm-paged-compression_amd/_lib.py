@@ -51,6 +51,10 @@ SIGNATURES = {
                                         c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                         c_int, c_void_p, c_int64, c_int, c_int, c_void_p, c_int,
                                         c_void_p]),
+    "pe_rope_reshape_and_cache": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
+                                          c_int, c_int, c_int, c_int, c_int, c_int64, c_int, c_int64,
+                                          c_int, c_void_p]),
     "pe_copy_blocks": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int,
                                c_void_p]),
     "pe_swap_blocks": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),

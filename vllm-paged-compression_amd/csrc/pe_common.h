@@ -88,6 +88,21 @@ __device__ __forceinline__ float round_to(float v) {
   return (float)(T)v;
 }
 
+// The same, with the 16-bit value made opaque to the optimiser: where the rounded value feeds
+// straight into further f32 arithmetic the compiler otherwise drops the down/up conversion pair
+// and contracts the surrounding multiply-add.
+template <typename T>
+__device__ __forceinline__ float round_to_strict(float v) {
+  if constexpr (sizeof(T) == 4) {
+    asm volatile("" : "+v"(v));
+    return v;
+  } else {
+    uint32_t bits = __builtin_bit_cast(uint16_t, (T)v);
+    asm volatile("" : "+v"(bits));
+    return (float)__builtin_bit_cast(T, (uint16_t)bits);
+  }
+}
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));

@@ -131,6 +131,63 @@ def reshape_and_cache(key: torch.Tensor, value: torch.Tensor, key_cache: torch.T
         H, D, bs, nb, _dtype_code(key), _stream(dev)), "reshape_and_cache")
 
 
+def rotary_embedding(positions: torch.Tensor, query: torch.Tensor, key: torch.Tensor, head_size: int,
+                     cos_sin_cache: torch.Tensor, is_neox: bool) -> None:
+    """In-place rotary embedding of query [T, Hq*D] (or [T, Hq, D]) and key; names and arguments
+    of ``vllm._custom_ops.rotary_embedding``."""
+    rotary_embedding_and_cache(positions, query, key, None, None, None, None, head_size,
+                               cos_sin_cache, is_neox)
+
+
+def rotary_embedding_and_cache(positions: torch.Tensor, query: torch.Tensor, key: torch.Tensor,
+                               value: Optional[torch.Tensor], key_cache: Optional[torch.Tensor],
+                               value_cache: Optional[torch.Tensor],
+                               slot_mapping: Optional[torch.Tensor], head_size: int,
+                               cos_sin_cache: torch.Tensor, is_neox: bool) -> None:
+    """Rotary embedding of query and key in place and, in the same launch, the KV write of the
+    rotated key and of value into the paged cache (``slot_mapping`` int64 [T], one slot per token,
+    negative = not cached).  With ``key_cache=None`` only the rotation runs."""
+    dev = _need_gpu(positions, query, key, value, key_cache, value_cache, slot_mapping, cos_sin_cache)
+    T = positions.numel()
+    q2 = query.reshape(T, -1) if query.dim() != 2 else query
+    k2 = key.reshape(T, -1) if key.dim() != 2 else key
+    if q2.data_ptr() != query.data_ptr() or k2.data_ptr() != key.data_ptr():
+        raise RuntimeError("rotary_embedding: query/key must be viewable as [num_tokens, heads*head_size]")
+    if q2.stride(1) != 1 or k2.stride(1) != 1 or q2.shape[1] % head_size or k2.shape[1] % head_size:
+        raise RuntimeError("rotary_embedding: rows must be dense multiples of head_size")
+    if positions.dtype != torch.int64 or not positions.is_contiguous():
+        raise RuntimeError("rotary_embedding: positions must be contiguous int64")
+    if cos_sin_cache.dim() != 2 or not cos_sin_cache.is_contiguous() or cos_sin_cache.dtype != query.dtype \
+            or key.dtype != query.dtype:
+        raise RuntimeError("rotary_embedding: cos_sin_cache [max_position, rot_dim] of the query dtype expected")
+    Hq, Hkv = q2.shape[1] // head_size, k2.shape[1] // head_size
+    bs = nb = 0
+    v_stride = 0
+    if key_cache is not None:
+        if value is None or value_cache is None or slot_mapping is None:
+            raise RuntimeError("rotary_embedding_and_cache: value, value_cache and slot_mapping needed")
+        v2 = value.reshape(T, -1) if value.dim() != 2 else value
+        if v2.data_ptr() != value.data_ptr() or v2.stride(1) != 1 or v2.shape[1] != Hkv * head_size \
+                or value.dtype != query.dtype:
+            raise RuntimeError("rotary_embedding_and_cache: value must be [num_tokens, kv_heads*head_size]")
+        if key_cache.dim() != 5 or value_cache.dim() != 4 or not key_cache.is_contiguous() \
+                or not value_cache.is_contiguous() or key_cache.dtype != query.dtype:
+            raise RuntimeError("rotary_embedding_and_cache: contiguous 5-d key_cache / 4-d value_cache expected")
+        nb, H, D, bs = value_cache.shape
+        if (H, D) != (Hkv, head_size):
+            raise RuntimeError("rotary_embedding_and_cache: cache geometry does not match key")
+        if slot_mapping.dtype != torch.int64 or slot_mapping.numel() != T or not slot_mapping.is_contiguous():
+            raise RuntimeError("rotary_embedding_and_cache: slot_mapping must be contiguous int64 [num_tokens]")
+        v_stride = v2.stride(0)
+        value = v2
+    lib = _lib.load()
+    _lib.check(lib.pe_rope_reshape_and_cache(
+        _p(q2), _p(k2), _p(value), _p(key_cache), _p(value_cache), _p(positions), _p(cos_sin_cache),
+        _p(slot_mapping), T, q2.stride(0), k2.stride(0), v_stride, Hq, Hkv, head_size,
+        cos_sin_cache.shape[1], 1 if is_neox else 0, cos_sin_cache.shape[0], bs, nb,
+        _dtype_code(query), _stream(dev)), "rope_reshape_and_cache")
+
+
 def _paged_attention(out, query, key_cache, value_cache, num_kv_heads, scale, block_tables,
                      seq_lens, block_size, max_seq_len, alibi_slopes, kv_cache_dtype, k_scale,
                      v_scale, blocksparse_vert_stride) -> None:
