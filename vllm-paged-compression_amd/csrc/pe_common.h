@@ -81,18 +81,13 @@ template <typename T>
 __device__ __forceinline__ T from_f32(float v) {
   return (T)v;
 }
-// round an f32 value to the storage type and back (what torch does after each
-// reduction on a low-precision tensor)
-template <typename T>
-__device__ __forceinline__ float round_to(float v) {
-  return (float)(T)v;
-}
-
-// The same, with the 16-bit value made opaque to the optimiser: where the rounded value feeds
+// Round an f32 value to the storage type and back (what torch does after each reduction on a
+// low-precision tensor, and what a kernel computing in the storage type does after each
+// operation).  The 16-bit value is made opaque to the optimiser: where the rounded value feeds
 // straight into further f32 arithmetic the compiler otherwise drops the down/up conversion pair
 // and contracts the surrounding multiply-add.
 template <typename T>
-__device__ __forceinline__ float round_to_strict(float v) {
+__device__ __forceinline__ float round_to(float v) {
   if constexpr (sizeof(T) == 4) {
     asm volatile("" : "+v"(v));
     return v;
@@ -101,6 +96,10 @@ __device__ __forceinline__ float round_to_strict(float v) {
     asm volatile("" : "+v"(bits));
     return (float)__builtin_bit_cast(T, (uint16_t)bits);
   }
+}
+template <typename T>
+__device__ __forceinline__ float round_to_strict(float v) {
+  return round_to<T>(v);
 }
 
 __device__ __forceinline__ float wave_max(float v) {
