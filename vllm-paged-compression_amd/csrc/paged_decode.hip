@@ -142,13 +142,13 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void paged_decode_mfma_kernel(
     const T* vb = value_cache + pb * kv_block_stride + head_off + v_lane_off;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      t.k[0][ks] = __builtin_bit_cast(vec8, *reinterpret_cast<const u32x4*>(ka + ks * 512));
-      t.k[1][ks] = __builtin_bit_cast(vec8, *reinterpret_cast<const u32x4*>(kb + ks * 512));
+      t.k[0][ks] = __builtin_bit_cast(vec8, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ka + ks * 512)));
+      t.k[1][ks] = __builtin_bit_cast(vec8, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kb + ks * 512)));
     }
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
-      t.v[0][dt] = __builtin_bit_cast(vec4, *reinterpret_cast<const u32x2*>(va + dt * 16 * BS));
-      t.v[1][dt] = __builtin_bit_cast(vec4, *reinterpret_cast<const u32x2*>(vb + dt * 16 * BS));
+      t.v[0][dt] = __builtin_bit_cast(vec4, __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(va + dt * 16 * BS)));
+      t.v[1][dt] = __builtin_bit_cast(vec4, __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(vb + dt * 16 * BS)));
     }
   };
 
