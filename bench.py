@@ -432,11 +432,13 @@ def main():
             "parallelism": (f"tp{world}" if tp else f"dp{world}") if world > 1 else "single",
             "oproj_allreduce": bool(wl.allreduce), **kv},
     }
+    main_budget = wl.budget
     if a.alt_evict > 0 and a.cache_budget == 0 and abs(a.alt_evict - a.evict) > 1e-9:
         # the same job at the metric's other eviction fraction (outside the timed region above)
         import copy
         a2 = copy.copy(a)
         a2.evict = a.alt_evict
+        main_budget = wl.budget
         del wl
         torch.cuda.empty_cache()
         wl2 = Workload(a2, dev, world if tp else 1, rank if tp else 0, dist.group.WORLD if tp else None)
@@ -462,7 +464,7 @@ def main():
         out["roofline"] = roof
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
-            out["cpu_baseline"] = cpu_baseline(a, wl.budget)
+            out["cpu_baseline"] = cpu_baseline(a, main_budget)
         except Exception as e:  # the baseline never decides the run
             out["cpu_baseline"] = {"value": None, "error": repr(e)}
     if rank == 0:

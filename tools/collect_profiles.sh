@@ -10,9 +10,9 @@ cd /tmp
 export TMPDIR=/tmp
 timeout -k 10 400 python3 "$R/bench.py" --steps 3 --warmup 1 > "$O/bench_n1.json" 2> "$O/bench_n1.err"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -o bench -- \
-    python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$O/bench_under_rocprof.json" 2> "$O/stats.err"
+    python3 "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --alt-evict 0 > "$O/bench_under_rocprof.json" 2> "$O/stats.err"
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fetch" -o fetch -- \
-    python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2> "$O/pmc_fetch.err"
+    python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --alt-evict 0 > /dev/null 2> "$O/pmc_fetch.err"
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$O/pmc_write" -o write -- \
-    python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2> "$O/pmc_write.err"
+    python3 "$R/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --alt-evict 0 > /dev/null 2> "$O/pmc_write.err"
 ls -R "$O" | head -40

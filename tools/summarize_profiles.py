@@ -50,7 +50,7 @@ def main():
     out = {
         "kernel": kernel,
         "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE -- python3 bench.py --steps 1 --warmup 0 "
-                   "--no-cpu-baseline (separate passes; average over every decode launch of the run)",
+                   "--no-cpu-baseline --alt-evict 0 (separate passes; average over every decode launch of the run)",
         "workload": cfg,
         "launches": {"fetch_pass": nf, "write_pass": nw},
         "FETCH_SIZE_kb_raw": fetch, "WRITE_SIZE_kb_raw": write,
