@@ -35,9 +35,26 @@ __device__ float block_score_wave(const T* __restrict__ base, int layout, int nu
       }
     } else {
       const T* v = base + (int64_t)p * head_size;  // dense rows (token-major or flat re-view)
-      for (int d = 0; d < head_size; ++d) {
-        const float x = to_f32(v[d]);
-        ss += x * x;
+      constexpr int X = 16 / sizeof(T);
+      if (head_size % X == 0 && ((uintptr_t)v % 16) == 0) {
+        // 16-byte loads, elements still accumulated in ascending order
+        for (int d = 0; d < head_size; d += X) {
+          union {
+            u32x4 raw;
+            T e[X];
+          } u;
+          u.raw = *reinterpret_cast<const u32x4*>(v + d);
+#pragma unroll
+          for (int e = 0; e < X; ++e) {
+            const float x = to_f32(u.e[e]);
+            ss += x * x;
+          }
+        }
+      } else {
+        for (int d = 0; d < head_size; ++d) {
+          const float x = to_f32(v[d]);
+          ss += x * x;
+        }
       }
     }
     norms[p] = round_to<T>(sqrtf(ss));
@@ -94,9 +111,25 @@ __global__ __launch_bounds__(64) void block_token_norm_sums_kernel(
       }
     } else {
       const T* v = base + (int64_t)p * head_size;
-      for (int d = 0; d < head_size; ++d) {
-        const float x = to_f32(v[d]);
-        ss += x * x;
+      constexpr int X = 16 / sizeof(T);
+      if (head_size % X == 0 && ((uintptr_t)v % 16) == 0) {
+        for (int d = 0; d < head_size; d += X) {
+          union {
+            u32x4 raw;
+            T e[X];
+          } u;
+          u.raw = *reinterpret_cast<const u32x4*>(v + d);
+#pragma unroll
+          for (int e = 0; e < X; ++e) {
+            const float x = to_f32(u.e[e]);
+            ss += x * x;
+          }
+        }
+      } else {
+        for (int d = 0; d < head_size; ++d) {
+          const float x = to_f32(v[d]);
+          ss += x * x;
+        }
       }
     }
     norms[p] = round_to<T>(sqrtf(ss));
