@@ -171,7 +171,11 @@ int pe_prompt_prune_gather(const void* key, const void* value, void* out_key,
 /* Kept-row index of the streamingLLM prompt prune for a batch of prompts
  * (kvcache_prunner.py:183-218): for request r with query rows [cu_q[r], cu_q[r+1]) and
  * kept rows [cu_kept[r], cu_kept[r+1]) writes src_index[cu_kept[r] + n] = absolute row
- * of the n-th kept token.  cu_q/cu_kept device int32[num_seqs+1]. */
+ * of the n-th kept token.  cu_q/cu_kept device int32[num_seqs+1].
+ * cache_budget == 0: the number of pruned tokens of request r is its length minus its kept
+ * length - the "percentage" prune type, whose prompt prune drops the oldest
+ * block_size*floor(int(middle/evict_freq)/block_size) tokens after the first block
+ * (vllm/attention/kvcache_prunner_old.py:137-200). */
 int pe_prompt_keep_index_streaming(int32_t* src_index, const int32_t* cu_q,
                                    const int32_t* cu_kept, int num_seqs, int cache_budget,
                                    int block_size, void* stream);
@@ -275,6 +279,39 @@ int pe_evict_select_compact(int32_t* rmv_idx_out, int32_t* out_tables,
                             const void* value_cache, int64_t kv_block_stride,
                             int num_kv_heads, int head_size, const float* new_scores,
                             int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Decode step of the "percentage" prune type (README-era flags --cache-prune-type percentage
+ * --evict-freq N; code kept in vllm/attention/kvcache_prunner_old.py:264-315,
+ * vllm/core/page_evict_kv_util_bak.py:66-106 and the decode loop left commented in
+ * vllm/attention/backends/torch_cuda_sdpa.py:1299-1373).  Every evict_freq blocks a sequence
+ * gives up num_block_merge-1 blocks: streamingLLM drops table columns
+ * [initial_blocks, initial_blocks+num_block_merge-1); value_l2 first merges the num_block_merge
+ * blocks from column initial_blocks into the first of them and drops the others.
+ *
+ * pe_merge_blocks_value_l2: for every listed row b (rows = device int32[n_rows] of batch
+ *   indices) and every KV head, reads the num_block_merge blocks block_tables[b][first_block ..)
+ *   of both caches, scores each of their tokens with ||V[token, head, :]||_2 (rounded to the
+ *   storage type), keeps the block_size highest (equal scores: the lowest token goes first),
+ *   and writes the kept K and V rows, in their original order, into block
+ *   block_tables[b][first_block].  Replaces prune_oldest_block + the write-back through
+ *   reshape_and_cache; the reference selects on a flat re-view of the cache blocks, repacks the
+ *   kept rows across heads and stores the kept keys as values (kvcache_prunner_old.py:312-313)
+ *   - this entry point implements the per-head selection those lines intend.
+ *   At most 256 tokens and 160 KiB of K+V per (row, head) merge.
+ * pe_block_table_remove_range: out_tables[b] = row b of block_tables without columns
+ *   [start[b], start[b]+n_remove) (start[b] < 0: row copied), out_width entries per row,
+ *   zero-filled past the source row.  The compaction step of that decode loop for any
+ *   num_block_merge (pe_evict_select_compact removes one column).
+ * ---------------------------------------------------------------------------------- */
+int pe_merge_blocks_value_l2(void* key_cache, void* value_cache, const int32_t* block_tables,
+                             const int32_t* rows, int n_rows, int max_blocks, int first_block,
+                             int num_block_merge, int num_kv_heads, int head_size,
+                             int block_size, int64_t kv_block_stride, int64_t kv_head_stride,
+                             int dtype, void* stream);
+int pe_block_table_remove_range(int32_t* out_tables, const int32_t* block_tables,
+                                const int32_t* start, int n_remove, int batch, int max_blocks,
+                                int out_width, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Rotary position embedding fused with the KV write - the two launches that precede the

@@ -391,6 +391,99 @@ class RandomVictimStream:
         return first
 
 
+# --------------------------------------------------------------------------- percentage prune type
+
+def percentage_prompt_slices(q_len: int, block_size: int, evict_freq: int, initial_blocks: int = 1,
+                             num_block_merge: int = 2) -> Tuple[int, int, int]:
+    """(end_first, end_middle, n_prune) of the README-era prompt prune,
+    vllm/attention/kvcache_prunner_old.py:143-176 (allocation side:
+    vllm/core/page_evict_kv_util_bak.py:10-31); n_prune = 0 for a prompt too short to prune."""
+    if q_len <= (initial_blocks + num_block_merge) * block_size:
+        return q_len, q_len, 0
+    rem = q_len % block_size
+    end_first = initial_blocks * block_size
+    end_mid = q_len - num_block_merge * block_size - rem
+    n_prune = int((end_mid - end_first) / evict_freq)
+    n_prune = block_size * (n_prune // block_size)
+    return end_first, end_mid, n_prune
+
+
+def percentage_keep_indices(q_len: int, block_size: int, evict_freq: int, initial_blocks: int = 1,
+                            num_block_merge: int = 2) -> List[int]:
+    """Kept token positions of that prune with the streamingLLM prompt method
+    (kvcache_prunner_old.py:176-196): the oldest n_prune middle tokens go."""
+    end_first, _, n_prune = percentage_prompt_slices(q_len, block_size, evict_freq, initial_blocks,
+                                                     num_block_merge)
+    return list(range(0, end_first)) + list(range(end_first + n_prune, q_len))
+
+
+def percentage_decode_blocks(seq_len: int, table_len: int, block_size: int, evict_freq: int,
+                             method: str, initial_blocks: int = 1, num_block_merge: int = 2):
+    """Decode step of the percentage type: (first freed table column or -1, columns freed,
+    columns merged).  Trigger: logical length a multiple of evict_freq blocks
+    (torch_cuda_sdpa.py:1310) and more than initial_blocks + num_block_merge blocks held
+    (page_evict_kv_util_bak.py:69,88).  streamingLLM frees [ib, ib+nbm-1) (:72-74); value_l2
+    merges [ib, ib+nbm) into block ib (kvcache_prunner_old.py:281-284) and frees [ib+1, ib+nbm)
+    (page_evict_kv_util_bak.py:91-93)."""
+    if seq_len % (block_size * evict_freq) != 0 or table_len <= initial_blocks + num_block_merge:
+        return -1, 0, None
+    if method == "streamingLLM":
+        return initial_blocks, num_block_merge - 1, None
+    return initial_blocks + 1, num_block_merge - 1, (initial_blocks, initial_blocks + num_block_merge)
+
+
+def merge_keep_sets(values: torch.Tensor, n_keep: int) -> List[List[int]]:
+    """Per head, the token indices that survive prune_oldest_block
+    (kvcache_prunner_old.py:302-309): scores ||V[t, h, :]||_2 (sum of squares in ascending
+    element order, f32, rounded to the storage type), the T - n_keep lowest go, equal scores
+    lowest token first (torch.topk leaves that order unspecified)."""
+    import numpy as np
+    T, H, D = values.shape
+    sq = values.float().numpy().astype(np.float32)
+    sq = sq * sq
+    ss = np.cumsum(sq, axis=-1, dtype=np.float32)[..., -1]
+    score = torch.from_numpy(np.sqrt(ss)).to(values.dtype).float()
+    order = torch.sort(score, dim=0, stable=True).indices  # ascending, [T, H]
+    keep = torch.ones((T, H), dtype=torch.bool)
+    keep.scatter_(0, order[:T - n_keep], False)
+    return [keep[:, h].nonzero().flatten().tolist() for h in range(H)]
+
+
+def merge_blocks_in_cache(key_cache: torch.Tensor, value_cache: torch.Tensor,
+                          block_ids: Sequence[int]) -> None:
+    """The decode-time merge on the paged layouts (key_cache [nb, H, D/x, bs, x], value_cache
+    [nb, H, D, bs]): logical rows of the listed blocks -> per-head selection -> the kept rows,
+    in order, into block_ids[0] (the write-back of torch_cuda_sdpa.py:1350-1363).  Per-head
+    selection on logical rows is what kvcache_prunner_old.py:302-313 intends; as written it
+    works on a flat re-view of the blocks, repacks rows across heads and returns the kept keys
+    as values."""
+    nb, H, Dx, bs, x = key_cache.shape
+    D = Dx * x
+    ids = torch.tensor(list(block_ids), dtype=torch.long)
+    # [n, H, D/x, bs, x] -> [n, bs, H, D]
+    k = key_cache[ids].permute(0, 3, 1, 2, 4).reshape(len(ids) * bs, H, D)
+    v = value_cache[ids].permute(0, 3, 1, 2).reshape(len(ids) * bs, H, D)
+    keep = merge_keep_sets(v, bs)
+    for h in range(H):
+        sel = torch.tensor(keep[h], dtype=torch.long)
+        key_cache[ids[0], h] = k[sel, h].reshape(bs, Dx, x).permute(1, 0, 2)
+        value_cache[ids[0], h] = v[sel, h].t()
+
+
+def table_remove_range(tables: torch.Tensor, start: Sequence[int], n_remove: int,
+                       out_width: int) -> torch.Tensor:
+    """Rows without columns [start, start+n_remove) (start < 0: unchanged), zero-filled."""
+    B, M = tables.shape
+    out = torch.zeros((B, out_width), dtype=torch.int32)
+    for b in range(B):
+        row = tables[b].tolist()
+        if start[b] >= 0:
+            row = row[:start[b]] + row[start[b] + n_remove:]
+        row = (row + [0] * out_width)[:out_width]
+        out[b] = torch.tensor(row, dtype=torch.int32)
+    return out
+
+
 # --------------------------------------------------------------------------- block-table counters
 
 class BlockTableCounters:

@@ -177,6 +177,89 @@ def main():
         json.dump({"steps": log, "after_append": after_append,
                    "seq0": list(mgr.get_reqid_and_seqid(0))}, f)
 
+    # ---- (vii) "percentage" prune type (README-era flags) ----------------------------------
+    # The code of this mode is kept in kvcache_prunner_old.py / page_evict_kv_util_bak.py.  The
+    # old pruner's __init__ reads names that only its __main__ block defines, so the object is
+    # made with __new__ and given the attributes its methods read; the util module imports two
+    # names from the vllm package (not importable here), which are supplied as stubs - its
+    # functions only read attributes of the config object they are handed.
+    import sys
+    import types
+    from types import SimpleNamespace
+    old = load("ref_kvcache_prunner_old", f"{ref}/vllm/attention/kvcache_prunner_old.py")
+    stub_utils = types.ModuleType("vllm.utils")
+    stub_utils.cdiv = lambda a, b: -(a // -b)
+    stub_cfg = types.ModuleType("vllm.config")
+    stub_cfg.PagedEvictConfig = object
+    saved = {k: sys.modules.get(k) for k in ("vllm", "vllm.utils", "vllm.config")}
+    sys.modules.update({"vllm": types.ModuleType("vllm"), "vllm.utils": stub_utils,
+                        "vllm.config": stub_cfg})
+    try:
+        bak = load("ref_page_evict_kv_util_bak", f"{ref}/vllm/core/page_evict_kv_util_bak.py")
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+    def old_pruner(prompt_method, decode_method, bs, freq, ib, nbm):
+        p = old.KVCachePruner.__new__(old.KVCachePruner)
+        p.cache_prune_type = "percentage"
+        p.prompt_evict_method, p.decode_evict_method = prompt_method, decode_method
+        p.orig_block_size, p.evict_frequency = bs, freq
+        p.initial_blocks, p.num_block_merge = ib, nbm
+        return p
+
+    pct = {"required_blocks": [], "streaming_keep": [], "decode_blocks": [], "util_blocks": []}
+    for bs in (8, 16):
+        for freq in (1, 2, 3, 4):
+            for nbm in (2, 3):
+                cfg = SimpleNamespace(initial_blocks=1, num_block_merge=nbm, original_block_size=bs,
+                                      prompt_evict_method="streamingLLM", cache_prune_type="percentage",
+                                      evict_freq=freq, decode_evict_method="streamingLLM")
+                for L in (1, bs, (1 + nbm) * bs, (1 + nbm) * bs + 1, 5 * bs, 100, 1024, 1030, 8192):
+                    nblk, ntok = bak.get_num_required_blocks_after_prune_promt(L, cfg)
+                    pct["required_blocks"].append([bs, freq, nbm, L, int(nblk), int(ntok)])
+    for (L, freq, bs, nbm) in [(80, 2, 16, 2), (100, 2, 16, 2), (100, 4, 16, 2), (1024, 2, 16, 2),
+                               (1024, 4, 16, 2), (1030, 4, 16, 2), (1030, 3, 16, 3), (48, 2, 16, 2),
+                               (49, 2, 16, 2), (200, 2, 8, 3), (77, 1, 8, 2)]:
+        p = old_pruner("streamingLLM", "streamingLLM", bs, freq, 1, nbm)
+        k, v = tagged_kv(L, 2, 8, torch.float32)
+        pk, pv = p.prune_prompt(k, v)
+        assert torch.equal(pk, pv)
+        src = (pk[:, 0, 0] * 64 + pk[:, 0, 1]).to(torch.int64).tolist()
+        pct["streaming_keep"].append({"L": L, "freq": freq, "bs": bs, "nbm": nbm, "kept": src})
+    for method in ("streamingLLM", "value_l2"):
+        for nbm in (2, 3, 4):
+            p = old_pruner("streamingLLM", method, 16, 2, 1, nbm)
+            pct["decode_blocks"].append([method, nbm, *[int(x) for x in p.get_blocks_to_prune_and_merge_decode(4096)]])
+            cfg = SimpleNamespace(initial_blocks=1, num_block_merge=nbm, original_block_size=16,
+                                  cache_prune_type="percentage", decode_evict_method=method)
+            pct["util_blocks"].append([method, nbm, *[int(x) for x in bak.get_blocks_to_prune(cfg, 4096)]])
+    with open(os.path.join(HERE, "percentage_tables.json"), "w") as f:
+        json.dump(pct, f)
+
+    # decode-time merge (prune_oldest_block): tie-free f32 inputs, the reference's output rows
+    # (kept (token, head) rows re-packed across heads, keys also returned as values - both are
+    # properties of the reference's code, kvcache_prunner_old.py:312-313)
+    out = {}
+    case = 0
+    for (nbm, bs, H, D) in [(2, 16, 4, 16), (3, 16, 2, 32), (2, 8, 3, 8), (4, 16, 2, 128)]:
+        for seed in (0, 1):
+            g = torch.Generator().manual_seed(9000 + 10 * case + seed)
+            T = nbm * bs
+            k = torch.rand(T, H, D, generator=g) * 2 - 1
+            v = torch.rand(T, H, D, generator=g) * 2 - 1
+            p = old_pruner("streamingLLM", "value_l2", bs, 2, 1, nbm)
+            _, _, prune_tokens = p.get_blocks_to_prune_and_merge_decode(4096)
+            pk, pv = p.prune_oldest_block(k, v, prune_tokens)
+            out[f"c{case}_meta"] = np.array([nbm, bs, H, D, prune_tokens])
+            out[f"c{case}_k"], out[f"c{case}_v"] = bits(k), bits(v)
+            out[f"c{case}_pk"], out[f"c{case}_pv"] = bits(pk), bits(pv)
+            case += 1
+    np.savez_compressed(os.path.join(HERE, "decode_merge.npz"), **out)
+
     # ---- (vi) reference CPU kernels: KV write + paged attention ----------------------
     lib = os.path.join(ROOT, "oracle", "_ref", "libpe_ref.so")
     torch.ops.load_library(lib)

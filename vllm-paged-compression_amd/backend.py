@@ -454,12 +454,19 @@ class PagedEvictImpl(_ImplBase):
             self.paged_evict_config = self.cache_config.paged_evict_config
             # README-era command lines name the prompt and the decode method separately
             # (--prompt-evict-method / --decode-evict-method); HEAD has one evict_method for both
-            prompt_method = kwargs.get("prompt_evict_method") or self.paged_evict_config.evict_method
-            self.kv_cache_pruner = KVCachePruner(
-                self.paged_evict_config.cache_prune_type, prompt_method,
-                self.cache_config.block_size, self.paged_evict_config.cache_budget,
-                self.paged_evict_config.initial_blocks,
-                cross_head_compat=self.compat.prompt_prune_cross_head)
+            pec = self.paged_evict_config
+            if pec.cache_prune_type == "percentage":
+                self.kv_cache_pruner = KVCachePruner(
+                    "percentage", pec.prompt_evict_method, self.cache_config.block_size,
+                    pec.cache_budget, pec.initial_blocks, evict_freq=pec.evict_freq,
+                    num_block_merge=pec.num_block_merge,
+                    decode_evict_method=pec.decode_evict_method)
+            else:
+                prompt_method = kwargs.get("prompt_evict_method") or pec.evict_method
+                self.kv_cache_pruner = KVCachePruner(
+                    pec.cache_prune_type, prompt_method, self.cache_config.block_size,
+                    pec.cache_budget, pec.initial_blocks,
+                    cross_head_compat=self.compat.prompt_prune_cross_head)
         self.block_l2norm_mgr = BlockL2NormManager()
         self.prefix: str = kwargs.get("prefix", "")
         self.layer_idx = _layer_index(self.prefix)
@@ -510,6 +517,9 @@ class PagedEvictImpl(_ImplBase):
                 self._pending_rmv, self._pending_reqs = dec["rmv"], dec.get("req_ids")
                 self._pending_readback = dec.get("readback")
                 self.reqids_mapping_rmv_blockIdx = dec["host_rmv"] or {}
+                if dec.get("merge") is not None:
+                    kc, vc = PagedAttention.split_kv_cache(kv_cache, self.num_kv_heads, self.head_size)
+                    self.kv_cache_pruner.merge_blocks_in_cache(kc, vc, dec["merge_tables"], dec["merge"])
             o = torch.empty_like(query) if output is None else output
             launcher.run(query, key, value, kv_cache, o)
             return o
@@ -557,7 +567,7 @@ class PagedEvictImpl(_ImplBase):
         max_q = max(seq_lens)
         cfg = self.paged_evict_config
         pruner = self.kv_cache_pruner
-        prune = self.enabled_paged_eviction and any(L > cfg.cache_budget for L in seq_lens)
+        prune = self.enabled_paged_eviction and any(pruner.prunes(L) for L in seq_lens)
 
         src_index = kept = None
         if prune:
@@ -639,6 +649,7 @@ class PagedEvictImpl(_ImplBase):
                 and parallel.group_rank(self.tp_group) != 0:
             return False
         return (self.enabled_paged_eviction and not self.compat.random_victim
+                and self.paged_evict_config.cache_prune_type == "budget"
                 and self.paged_evict_config.evict_method in ("local", "global")
                 and (self.layer_idx <= 0 or self.compat.per_layer_decision))
 
@@ -706,6 +717,11 @@ class PagedEvictImpl(_ImplBase):
             self._pending_rmv, self._pending_reqs = dec["rmv"], dec.get("req_ids")
             self._pending_readback = dec.get("readback")
             self.reqids_mapping_rmv_blockIdx = dec["host_rmv"] or {}
+            if dec.get("merge") is not None:
+                # percentage type, value_l2: this layer's blocks are merged before attention reads
+                # them (the step's token goes to the last block, which is never one of them)
+                self.kv_cache_pruner.merge_blocks_in_cache(key_cache, value_cache,
+                                                           dec["merge_tables"], dec["merge"])
         # the decode kernels take a maximum length only to size their split-KV work: give them
         # the longest PHYSICAL length (the reference passes the logical one, :446-447, which
         # over-states what is read once blocks have been evicted)
@@ -762,6 +778,11 @@ class PagedEvictImpl(_ImplBase):
             table_of = lambda i: mapping[keys[i][0]][keys[i][1]]  # noqa: E731
             table_lens = np.fromiter((len(table_of(i)) for i in range(n_seqs)), dtype=np.int64,
                                      count=n_seqs)
+        if cfg.cache_prune_type == "percentage":
+            dec = self._decode_decision_percentage(dm, L, table_lens, req_ids)
+            if not self.compat.per_layer_decision:
+                step["decode"] = dec
+            return dec
         if self._score_table is not None:
             # a decode step lists every running sequence: whoever is absent has finished
             self._score_table.retain_only(keys)
@@ -860,6 +881,36 @@ class PagedEvictImpl(_ImplBase):
                 dec["readback"] = staging.AsyncReadback(dec["rmv"])
         if not self.compat.per_layer_decision:
             step["decode"] = dec
+        return dec
+
+    def _decode_decision_percentage(self, dm, L: np.ndarray, table_lens: np.ndarray,
+                                    req_ids: List[str]) -> Dict[str, Any]:
+        """Decode step of the percentage prune type (kvcache_prunner_old.py:264-295,
+        page_evict_kv_util_bak.py:66-106, trigger torch_cuda_sdpa.py:1310): nothing depends on
+        the data, so the decision is host arithmetic; the device compacts the tables and, for
+        value_l2, every layer merges its own blocks."""
+        cfg = self.paged_evict_config
+        bs = self.cache_config.block_size
+        ib, nbm = cfg.initial_blocks, cfg.num_block_merge
+        # on a trigger step the last block has just been filled, so a sequence holds
+        # table_len * block_size tokens: "more than initial_blocks + num_block_merge blocks"
+        trig_np = (L % (bs * cfg.evict_freq) == 0) & (table_lens > ib + nbm)
+        dec: Dict[str, Any] = {"rmv": None, "tables": None, "zero_slots": None, "host_rmv": None,
+                               "req_ids": None, "merge": None}
+        if not trig_np.any():
+            return dec
+        dev = dm.block_tables.device
+        value_l2 = cfg.decode_evict_method == "value_l2"
+        first_freed = ib + 1 if value_l2 else ib
+        n_remove = nbm - 1
+        M = dm.block_tables.shape[1]
+        width = min(max(int((table_lens - trig_np * n_remove).max()), 1), M)
+        start = staging.upload_i32(np.where(trig_np, first_freed, -1), dev)
+        dec["tables"] = ops.block_table_remove_range(dm.block_tables, start, n_remove, width)
+        dec["host_rmv"] = {int(i): (req_ids[i], first_freed) for i in np.nonzero(trig_np)[0]}
+        if value_l2:
+            dec["merge"] = staging.upload_i32(np.nonzero(trig_np)[0], dev)
+            dec["merge_tables"] = dm.block_tables
         return dec
 
 

@@ -147,6 +147,13 @@ class BatchEvictionScheduler:
         gaps (block_table.py:456-466)."""
         if not reqids_to_rmv_block_idx:
             return
+        cfg = self.paged_evict_config
+        # percentage prune type: num_block_merge-1 consecutive blocks go, from the reported index
+        n = cfg.num_block_merge - 1 if cfg is not None and cfg.cache_prune_type == "percentage" else 1
+        for _ in range(n):
+            self._free_column(reqids_to_rmv_block_idx)
+
+    def _free_column(self, reqids_to_rmv_block_idx: Dict[int, Tuple[str, int]]) -> None:
         bs = self.block_size
         items = list(reqids_to_rmv_block_idx.values())
         rows = np.fromiter((self._row_of_req[r] for r, _ in items), dtype=np.int64, count=len(items))

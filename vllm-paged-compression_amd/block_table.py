@@ -203,5 +203,10 @@ class EvictionScheduler:
 
     def commit(self, reqids_to_rmv_block_idx: Dict[int, Tuple[str, int]]) -> None:
         """Apply a step's ``get_rmv_block_idx()`` result ({batch_idx: (request_id, block_idx)})."""
+        cfg = self.block_manager.paged_evict_config
+        # percentage prune type: a decode prune frees num_block_merge-1 consecutive blocks
+        # starting at the reported index (page_evict_kv_util_bak.py:66-106)
+        n = cfg.num_block_merge - 1 if cfg is not None and cfg.cache_prune_type == "percentage" else 1
         for _, (request_id, idx) in reqids_to_rmv_block_idx.items():
-            self.update_block_tables(request_id, idx)
+            for _ in range(n):
+                self.update_block_tables(request_id, idx)

@@ -14,32 +14,64 @@ from typing import Optional
 logger = logging.getLogger(__name__)
 
 EVICT_METHODS = ("streamingLLM", "streamingLLM-1", "inverse_key_l2", "local", "global")
+# methods of the "percentage" prune type (README-era --prompt-evict-method / --decode-evict-method)
+PERCENTAGE_PROMPT_METHODS = ("streamingLLM",)
+PERCENTAGE_DECODE_METHODS = ("streamingLLM", "value_l2")
 
 
 class PagedEvictConfig:
     """--enable-paged-eviction flags.
 
     disable_evict_prefill: attend the full prompt, prune when writing the cache
-    cache_prune_type:      "budget" ("percentage" is parsed but rejected, as at the reference's HEAD)
+    cache_prune_type:      "budget", or "percentage" when ``evict_freq`` is given (the reference's
+                           HEAD parses "percentage" and then rejects it: the five positional
+                           arguments alone behave exactly like that)
     evict_method:          one of EVICT_METHODS
     cache_budget:          tokens kept per sequence (clamped up to 128)
     topk_blocks:           candidate window of "local" (> 1); forced to -1 for "global"
+
+    Keyword-only, the flags HEAD's constructor has commented out (config.py:945-958,
+    engine/arg_utils.py:1004-1006,1138-1141) and the README's command lines still pass:
+    evict_freq:            "percentage": the prompt prune drops 1/evict_freq of the middle tokens
+                           (whole blocks) and a decode step prunes every evict_freq blocks
+    num_block_merge:       blocks a decode prune works on: num_block_merge-1 of them are freed
+    prompt_evict_method / decode_evict_method: the two method flags of that era
+                           ("streamingLLM"; "streamingLLM" or "value_l2"); default evict_method
     """
 
     def __init__(self, disable_evict_prefill: bool, cache_prune_type: str, evict_method: str,
-                 cache_budget: int, topk_blocks: int) -> None:
+                 cache_budget: int, topk_blocks: int, *, evict_freq: Optional[int] = None,
+                 num_block_merge: int = 2, prompt_evict_method: Optional[str] = None,
+                 decode_evict_method: Optional[str] = None) -> None:
         self.disable_evict_prefill = disable_evict_prefill
         self.cache_prune_type = cache_prune_type
         self.evict_method = evict_method
         self.cache_budget = cache_budget
         self.topk_blocks = topk_blocks
         self.initial_blocks = 1  # blocks at the head of the sequence that are never evicted
+        self.evict_freq = evict_freq
+        self.num_block_merge = num_block_merge
+        self.prompt_evict_method = prompt_evict_method or evict_method
+        self.decode_evict_method = decode_evict_method or evict_method
         self._verify_args()
 
     def _verify_args(self) -> None:
         if self.cache_prune_type not in ("percentage", "budget"):
             raise ValueError("Cache prune type must be either 'percentage' or 'budget'. Got "
                              f"{self.cache_prune_type}.")
+        if self.cache_prune_type == "percentage" and self.evict_freq is not None:
+            if self.evict_freq < 1:
+                raise ValueError(f"Evict frequency must be positive. Got {self.evict_freq}.")
+            if self.num_block_merge < 2:
+                raise ValueError("Number of blocks to merge must be at least 2. Got "
+                                 f"{self.num_block_merge}.")
+            if self.prompt_evict_method not in PERCENTAGE_PROMPT_METHODS:
+                raise ValueError(f"Unknown prompt evict method {self.prompt_evict_method!r} for the "
+                                 f"percentage prune type; expected one of {PERCENTAGE_PROMPT_METHODS}.")
+            if self.decode_evict_method not in PERCENTAGE_DECODE_METHODS:
+                raise ValueError(f"Unknown decode evict method {self.decode_evict_method!r} for the "
+                                 f"percentage prune type; expected one of {PERCENTAGE_DECODE_METHODS}.")
+            return
         assert self.cache_prune_type == "budget", \
             "Cache prune type must be 'budget' for paged compression now."
         if self.evict_method not in EVICT_METHODS:
@@ -58,9 +90,14 @@ class PagedEvictConfig:
             self.topk_blocks = -1
 
     def __repr__(self) -> str:
+        extra = ""
+        if self.cache_prune_type == "percentage":
+            extra = (f", evict_freq={self.evict_freq}, num_block_merge={self.num_block_merge}, "
+                     f"prompt_evict_method={self.prompt_evict_method!r}, "
+                     f"decode_evict_method={self.decode_evict_method!r}")
         return (f"PagedEvictConfig(disable_evict_prefill={self.disable_evict_prefill}, "
                 f"cache_prune_type={self.cache_prune_type!r}, evict_method={self.evict_method!r}, "
-                f"cache_budget={self.cache_budget}, topk_blocks={self.topk_blocks})")
+                f"cache_budget={self.cache_budget}, topk_blocks={self.topk_blocks}{extra})")
 
 
 def budget_from_percentage(evict_fraction: float, input_len: int, block_size: int) -> int:

@@ -177,16 +177,20 @@ __global__ void keep_index_streaming_kernel(int32_t* __restrict__ src_index,
   const int r = blockIdx.y;
   const int q0 = cu_q[r], L = cu_q[r + 1] - q0;
   const int k0 = cu_kept[r], n_kept = cu_kept[r + 1] - k0;
-  int n_prune = 0, end_mid = 0;
-  if (L > budget) {
+  int n_prune = 0;
+  if (budget == 0) {
+    // pruned count given by the caller's kept lengths (percentage prune type: the oldest
+    // middle tokens go, kvcache_prunner_old.py:166-176)
+    n_prune = L > n_kept ? L - n_kept : 0;
+  } else if (L > budget) {
     const int rem = L % bs;
-    end_mid = L - bs - rem;
+    const int end_mid = L - bs - rem;
     n_prune = (end_mid - bs) - (budget - 2 * bs);
     if (n_prune < 0) n_prune = 0;
   }
   for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < n_kept; n += gridDim.x * blockDim.x) {
     // kept = [0, bs) U [bs + n_prune, end_mid) U [end_mid, L): a single jump after bs
-    const int src = (L > budget && n >= bs) ? n + n_prune : n;
+    const int src = n >= bs ? n + n_prune : n;
     src_index[k0 + n] = q0 + src;
   }
 }
@@ -306,8 +310,10 @@ int pe_prompt_keep_index_streaming(int32_t* src_index, const int32_t* cu_q, cons
   PE_REQUIRE(num_seqs >= 0, PE_ERR_INVALID_ARG, "negative num_seqs");
   if (num_seqs == 0) return PE_OK;
   PE_REQUIRE(src_index && cu_q && cu_kept, PE_ERR_INVALID_ARG, "keep_index: null pointer");
-  PE_REQUIRE(block_size > 0 && cache_budget >= 3 * block_size, PE_ERR_INVALID_ARG,
-             "cache budget must be at least 3 blocks (kvcache_prunner.py:15)");
+  PE_REQUIRE(block_size > 0 && (cache_budget == 0 || cache_budget >= 3 * block_size),
+             PE_ERR_INVALID_ARG,
+             "cache budget must be at least 3 blocks (kvcache_prunner.py:15), or 0 when the kept "
+             "lengths alone define the prune");
   PE_REQUIRE(num_seqs <= 65535, PE_ERR_UNSUPPORTED, "too many prompts in one call");
   hipLaunchKernelGGL(keep_index_streaming_kernel, dim3(32, (unsigned)num_seqs), dim3(256), 0,
                      static_cast<hipStream_t>(stream), src_index, cu_q, cu_kept, cache_budget,

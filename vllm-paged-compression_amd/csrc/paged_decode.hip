@@ -29,7 +29,17 @@
 
 namespace pe {
 
-constexpr int DEC_WAVES = 4;
+// Build-time tunables of the MFMA path (the defaults are the measured optimum on MI355X)
+#ifndef PE_DEC_WAVES
+#define PE_DEC_WAVES 4  // waves per workgroup
+#endif
+#ifndef PE_DEC_TILES
+#define PE_DEC_TILES 2  // 32-token tiles in flight per wave (head sizes up to 128)
+#endif
+#ifndef PE_DEC_OCC
+#define PE_DEC_OCC 2  // waves per SIMD the register budget is set for (head sizes up to 128)
+#endif
+constexpr int DEC_WAVES = PE_DEC_WAVES;
 constexpr int DEC_THREADS = DEC_WAVES * 64;
 constexpr float NEG_BIG = -1.0e30f;
 
@@ -43,7 +53,7 @@ struct DecTile {
 __host__ __device__ inline int64_t ws_stride(int head_size) { return head_size + 2; }
 
 template <typename T, int HEAD_SIZE>
-__global__ __launch_bounds__(DEC_THREADS, 2) void paged_decode_mfma_kernel(
+__global__ __launch_bounds__(DEC_THREADS, (HEAD_SIZE <= 128 ? PE_DEC_OCC : 2)) void paged_decode_mfma_kernel(
     T* __restrict__ out, float* __restrict__ ws, const T* __restrict__ query,
     const T* __restrict__ key_cache, const T* __restrict__ value_cache,
     const int32_t* __restrict__ block_tables, const int32_t* __restrict__ seq_lens,
@@ -215,7 +225,7 @@ __global__ __launch_bounds__(DEC_THREADS, 2) void paged_decode_mfma_kernel(
   };
 
   // ---- main loop: waves interleave over the split's block pairs ----------------------
-  if constexpr (HEAD_SIZE <= 128) {
+  if constexpr (HEAD_SIZE <= 128 && PE_DEC_TILES == 2) {
     // two tiles in flight per wave (the next pair's 16 KB is requested before the current
     // pair is consumed)
     DecTile<T, HEAD_SIZE> t0, t1;

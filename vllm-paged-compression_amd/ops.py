@@ -484,6 +484,50 @@ def evict_select_compact(block_tables: torch.Tensor, seq_lens: torch.Tensor,
     return rmv, out_tables, zero
 
 
+def merge_blocks_value_l2(key_cache: torch.Tensor, value_cache: torch.Tensor,
+                          block_tables: torch.Tensor, rows: torch.Tensor, first_block: int,
+                          num_block_merge: int) -> None:
+    """In place, for every batch row listed in ``rows`` (int32) and every KV head: merge the
+    ``num_block_merge`` blocks from table column ``first_block`` into the first of them, keeping
+    the block_size tokens with the highest ||V||_2 in their original order (the decode-time
+    merge of the percentage prune type, kvcache_prunner_old.py:264-315)."""
+    dev = _need_gpu(key_cache, value_cache, block_tables, rows)
+    nb, Hkv, D, bs = value_cache.shape
+    if key_cache.dtype != value_cache.dtype or key_cache.shape[0] != nb or key_cache.shape[1] != Hkv:
+        raise RuntimeError("merge_blocks_value_l2: key/value cache mismatch")
+    if value_cache.stride(3) != 1 or value_cache.stride(2) != bs or \
+            key_cache.stride(0) != value_cache.stride(0) or key_cache.stride(1) != value_cache.stride(1):
+        raise RuntimeError("merge_blocks_value_l2: paged cache layout expected")
+    for t in (block_tables, rows):
+        if t.dtype != torch.int32 or not t.is_contiguous():
+            raise RuntimeError("merge_blocks_value_l2: int32 contiguous tensors expected")
+    lib = _lib.load()
+    _lib.check(lib.pe_merge_blocks_value_l2(
+        _p(key_cache), _p(value_cache), _p(block_tables), _p(rows), rows.numel(),
+        block_tables.shape[1], first_block, num_block_merge, Hkv, D, bs, value_cache.stride(0),
+        value_cache.stride(1), _dtype_code(value_cache), _stream(dev)), "merge_blocks_value_l2")
+
+
+def block_table_remove_range(block_tables: torch.Tensor, start: torch.Tensor, n_remove: int,
+                             out_width: Optional[int] = None) -> torch.Tensor:
+    """Rows of ``block_tables`` without columns [start[b], start[b]+n_remove) (start[b] < 0: row
+    kept as is); int32 [B, out_width], out_width defaults to M - n_remove."""
+    dev = _need_gpu(block_tables, start)
+    B, M = block_tables.shape
+    for t in (block_tables, start):
+        if t.dtype != torch.int32 or not t.is_contiguous():
+            raise RuntimeError("block_table_remove_range: int32 contiguous tensors expected")
+    if start.numel() != B:
+        raise RuntimeError("block_table_remove_range: one start column per row expected")
+    if out_width is None:
+        out_width = max(M - n_remove, 1)
+    out = torch.empty((B, out_width), dtype=torch.int32, device=dev)
+    lib = _lib.load()
+    _lib.check(lib.pe_block_table_remove_range(_p(out), _p(block_tables), _p(start), n_remove, B, M,
+                                               out_width, _stream(dev)), "block_table_remove_range")
+    return out
+
+
 def decode_step(out, query, key, value, key_cache, value_cache, slot_mapping, num_kv_heads, scale,
                 block_tables, seq_lens, block_size, max_seq_len, alibi_slopes=None) -> None:
     """KV write of a decode batch + paged attention in ONE launch (see pe_decode_step).  query

@@ -1,5 +1,6 @@
-"""Prompt length after pruning, for block allocation.  Same name and return value as the
-reference's vllm/core/page_evict_kv_util.py:6-36."""
+"""Prompt length after pruning, for block allocation, and the blocks a decode prune frees.
+Same names and return values as the reference's vllm/core/page_evict_kv_util.py:6-36 (budget
+prune type) and vllm/core/page_evict_kv_util_bak.py:6-106 (percentage prune type)."""
 from typing import Tuple
 
 
@@ -7,11 +8,29 @@ def cdiv(a: int, b: int) -> int:
     return -(a // -b)
 
 
+def percentage_pruned_prompt(q_len: int, block_size: int, evict_freq: int, initial_blocks: int,
+                             num_block_merge: int) -> Tuple[int, int]:
+    """(tokens pruned, tokens kept) of a q_len-token prompt under the percentage prune type
+    (page_evict_kv_util_bak.py:10-31, kvcache_prunner_old.py:143-176): the first
+    initial_blocks blocks and the last num_block_merge blocks (+ the remainder) stay, and of
+    the middle the oldest block_size*floor(int(middle/evict_freq)/block_size) tokens go."""
+    if q_len <= (initial_blocks + num_block_merge) * block_size:
+        return 0, q_len
+    rem = q_len % block_size
+    middle = (q_len - num_block_merge * block_size - rem) - initial_blocks * block_size
+    pruned = block_size * (int(middle / evict_freq) // block_size)
+    return pruned, q_len - pruned
+
+
 def get_num_required_blocks_after_prune_promt(q_len: int, paged_evict_config,
                                               block_size: int) -> Tuple[int, int]:
-    """(number of blocks, number of tokens) a q_len-token prompt occupies once pruned to
-    the cache budget: first block + budgeted middle + last block (+ remainder)."""
+    """(number of blocks, number of tokens) a q_len-token prompt occupies once pruned.
+    Budget: first block + budgeted middle + last block (+ remainder)."""
     cfg = paged_evict_config
+    if cfg.cache_prune_type == "percentage":
+        _, kept = percentage_pruned_prompt(q_len, block_size, cfg.evict_freq, cfg.initial_blocks,
+                                           cfg.num_block_merge)
+        return cdiv(kept, block_size), kept
     if q_len < cfg.cache_budget:
         return cdiv(q_len, block_size), q_len
     if cfg.evict_method not in ("streamingLLM", "streamingLLM-1", "inverse_key_l2", "global",
@@ -26,3 +45,31 @@ def get_num_required_blocks_after_prune_promt(q_len: int, paged_evict_config,
     middle_kept = max(cfg.cache_budget - head - block_size, 0)
     total = head + middle_kept + (q_len - end_middle)
     return cdiv(total, block_size), total
+
+
+def get_blocks_to_prune(paged_evict_config, seq_kv_len: int, block_size: int) -> Tuple[int, int, int]:
+    """(first block index, end block index, tokens pruned) of the block-table columns a decode
+    prune of the percentage type frees, (-1, -1, 0) for a sequence too short to prune
+    (page_evict_kv_util_bak.py:66-94; there the short-sequence result is overwritten by the
+    lines that follow it - the early return is what those lines are for).
+    streamingLLM frees [initial_blocks, initial_blocks + num_block_merge - 1); value_l2 merges
+    num_block_merge blocks into block initial_blocks and frees the num_block_merge - 1 after it."""
+    cfg = paged_evict_config
+    if cfg.cache_prune_type != "percentage":
+        raise ValueError("get_blocks_to_prune describes the percentage prune type")
+    ib, nbm = cfg.initial_blocks, cfg.num_block_merge
+    if seq_kv_len <= (ib + nbm) * block_size:
+        return -1, -1, 0
+    if cfg.decode_evict_method == "streamingLLM":
+        return ib, ib + nbm - 1, (nbm - 1) * block_size
+    return ib + 1, ib + nbm, (nbm - 1) * block_size
+
+
+def percentage_decode_trigger(paged_evict_config, seq_len: int, seq_kv_len: int,
+                              block_size: int) -> bool:
+    """A decode step of the percentage type prunes when the logical length (the step's token
+    included) reaches a multiple of evict_freq blocks (torch_cuda_sdpa.py:1310) and the
+    sequence physically holds more than initial_blocks + num_block_merge blocks."""
+    cfg = paged_evict_config
+    return (seq_len % (block_size * cfg.evict_freq) == 0
+            and seq_kv_len > (cfg.initial_blocks + cfg.num_block_merge) * block_size)

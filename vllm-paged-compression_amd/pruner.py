@@ -1,5 +1,7 @@
 """KVCachePruner: prompt pruning and block scoring, with the constructor and method names of
-the reference's vllm/attention/kvcache_prunner.py:6-326, over the HIP operators.
+the reference's vllm/attention/kvcache_prunner.py:6-326, over the HIP operators.  The
+"percentage" prune type (README-era flags; vllm/attention/kvcache_prunner_old.py:137-315) is
+the same object with ``evict_freq`` / ``num_block_merge`` given.
 
 Length arithmetic (``get_pruned_length``) runs on the host; everything that touches K/V
 runs on the GPU: the kept rows are described by an int32 index built on the device
@@ -14,6 +16,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import ops
+from .page_evict_kv_util import percentage_pruned_prompt
 
 _STREAMING = ("streamingLLM", "streamingLLM-1")
 _TOKEN_LEVEL = ("local", "global", "inverse_key_l2")
@@ -22,12 +25,9 @@ _TOKEN_LEVEL = ("local", "global", "inverse_key_l2")
 class KVCachePruner:
 
     def __init__(self, cache_prune_type: str, evict_method: str, block_size: int,
-                 cache_budget: int, initial_blocks: int, *, cross_head_compat: bool = False):
-        assert cache_prune_type == "budget"
-        assert cache_budget >= 3 * block_size, \
-            "Cache budget must be at least 3 times the original block size"
-        if evict_method not in _STREAMING + _TOKEN_LEVEL:
-            raise ValueError(f"Unknown eviction method: {evict_method}")
+                 cache_budget: int, initial_blocks: int, *, cross_head_compat: bool = False,
+                 evict_freq: Optional[int] = None, num_block_merge: int = 2,
+                 decode_evict_method: Optional[str] = None):
         self.cache_prune_type = cache_prune_type
         self.evict_method = evict_method
         self.orig_block_size = block_size
@@ -35,16 +35,61 @@ class KVCachePruner:
         self.sub_evict_method = "value_l2"   # score used by "global" and "local"
         self.initial_blocks = initial_blocks
         self.cross_head_compat = cross_head_compat
+        self.evict_frequency = evict_freq
+        self.num_block_merge = num_block_merge
+        self.prompt_evict_method = evict_method
+        self.decode_evict_method = decode_evict_method or evict_method
+        if cache_prune_type == "percentage":
+            assert evict_freq is not None and evict_freq >= 1 and num_block_merge >= 2
+            assert initial_blocks == 1, "the kept-row index jumps after the first block"
+            if evict_method != "streamingLLM":
+                raise ValueError(f"Unknown prompt eviction method for the percentage type: {evict_method}")
+            if self.decode_evict_method not in ("streamingLLM", "value_l2"):
+                raise ValueError("Unknown decode eviction method for the percentage type: "
+                                 f"{self.decode_evict_method}")
+            return
+        assert cache_prune_type == "budget"
+        assert cache_budget >= 3 * block_size, \
+            "Cache budget must be at least 3 times the original block size"
+        if evict_method not in _STREAMING + _TOKEN_LEVEL:
+            raise ValueError(f"Unknown eviction method: {evict_method}")
 
     # ------------------------------------------------------------------ host arithmetic
     def get_pruned_length(self, seq_len: int) -> int:
-        """Tokens kept of a seq_len-token prompt: first block + budgeted middle + last block
-        (+ remainder)."""
+        """Tokens kept of a seq_len-token prompt.  Budget: first block + budgeted middle + last
+        block (+ remainder).  Percentage: everything but the oldest 1/evict_freq of the middle
+        (whole blocks)."""
+        if self.cache_prune_type == "percentage":
+            return percentage_pruned_prompt(seq_len, self.orig_block_size, self.evict_frequency,
+                                            self.initial_blocks, self.num_block_merge)[1]
         if seq_len <= self.cache_budget:
             return seq_len
         bs = self.orig_block_size
         end_middle = seq_len - bs - seq_len % bs
         return bs + max(self.cache_budget - 2 * bs, 0) + (seq_len - end_middle)
+
+    def prunes(self, seq_len: int) -> bool:
+        """Whether a prompt of this length loses tokens."""
+        if self.cache_prune_type == "percentage":
+            return self.get_pruned_length(seq_len) < seq_len
+        return seq_len > self.cache_budget
+
+    def get_blocks_to_prune_and_merge_decode(self, seq_kv_len: int) -> Tuple[int, int, int]:
+        """(first, end, tokens pruned) of the block-table columns a decode prune of the
+        percentage type works on: num_block_merge blocks from initial_blocks, of which
+        num_block_merge-1 blocks' worth of tokens go (kvcache_prunner_old.py:264-295)."""
+        assert self.cache_prune_type == "percentage"
+        s = self.initial_blocks
+        return s, s + self.num_block_merge, (self.num_block_merge - 1) * self.orig_block_size
+
+    def merge_blocks_in_cache(self, key_cache: torch.Tensor, value_cache: torch.Tensor,
+                              block_tables: torch.Tensor, rows: torch.Tensor) -> None:
+        """value_l2 decode prune for the batch rows listed in ``rows``: per KV head the
+        block_size highest-||V|| tokens of the merged blocks survive, in order, in the first of
+        them (prune_oldest_block + write-back, kvcache_prunner_old.py:297-315 and
+        torch_cuda_sdpa.py:1331-1363, in place on the paged cache)."""
+        s, _, _ = self.get_blocks_to_prune_and_merge_decode(0)
+        ops.merge_blocks_value_l2(key_cache, value_cache, block_tables, rows, s, self.num_block_merge)
 
     # ------------------------------------------------------------------ device index
     def keep_index(self, key: torch.Tensor, value: torch.Tensor, seq_lens: Sequence[int],
@@ -60,7 +105,10 @@ class KVCachePruner:
         if cu_kept is None:
             cu_kept = _cumsum(kept, dev)
         total = sum(kept)
-        if self.evict_method in _STREAMING:
+        if self.cache_prune_type == "percentage":
+            # budget 0: the pruned count of each prompt is its length minus its kept length
+            idx = ops.prompt_keep_index_streaming(cu_q, cu_kept, total, 0, self.orig_block_size)
+        elif self.evict_method in _STREAMING:
             idx = ops.prompt_keep_index_streaming(cu_q, cu_kept, total, self.cache_budget,
                                                   self.orig_block_size)
         else:
@@ -79,7 +127,7 @@ class KVCachePruner:
     def prune_prompt(self, key_tensor: torch.Tensor, value_tensor: torch.Tensor):
         """Prune one request's prompt K/V ([L, H, D]) -> ([n_kept, H, D], same)."""
         L = key_tensor.shape[0]
-        if L <= self.cache_budget:
+        if not self.prunes(L):
             return key_tensor, value_tensor
         idx, _ = self.keep_index(key_tensor, value_tensor, [L])
         return self._gather(key_tensor, value_tensor, idx)
@@ -95,7 +143,7 @@ class KVCachePruner:
                             seq_lens: Sequence[int]):
         """All prompts of a prefill batch in one go (the reference loops over requests on 8
         side streams, torch_cuda_sdpa.py:1222-1296).  Returns (keys, values, kept lengths)."""
-        if all(L <= self.cache_budget for L in seq_lens):
+        if not any(self.prunes(L) for L in seq_lens):
             return key, value, list(seq_lens)
         idx, kept = self.keep_index(key, value, seq_lens)
         k, v = self._gather(key, value, idx)
