@@ -47,7 +47,19 @@ def parse():
     ap.add_argument("--prompt-evict-method", default="streamingLLM")
     ap.add_argument("--decode-evict-method", default="value_l2",
                     help="streamingLLM | streamingLLM-1 | value_l2 (= global) | local | global")
-    ap.add_argument("--evict-freq", type=int, default=0, help="accepted for README compatibility; unused")
+    ap.add_argument("--cache-prune-type", choices=["budget", "percentage"], default="budget",
+                    help="percentage = the README-era mode driven by --evict-freq / --num-block-merge "
+                         "(prompt: 1/evict_freq of the middle goes; decode: every evict_freq blocks "
+                         "num_block_merge blocks are merged into one)")
+    ap.add_argument("--evict-freq", type=int, default=0,
+                    help="percentage prune type: the divisor above (README: 2 and 4); ignored for budget")
+    ap.add_argument("--num-block-merge", type=int, default=2)
+    # flags of the reference's benchmark_throughput.py command lines, accepted so that the README
+    # commands can be pasted; they select nothing here
+    ap.add_argument("--enable-paged-eviction", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--enforce-eager", action="store_true", help=argparse.SUPPRESS)
+    for flag in ("--backend", "--model", "--distributed-executor-backend", "--tensor-parallel-size"):
+        ap.add_argument(flag, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--evict-prefill", action="store_true",
                     help="prune before prefill attention (default: attend the full prompt, as the "
                          "reference's scripts do with --disable-evict-prefill)")
@@ -91,7 +103,19 @@ class Workload:
         self.cfg = None
         self.budget = 0
         method = {"value_l2": "global"}.get(a.decode_evict_method, a.decode_evict_method)
-        if a.evict > 0 or a.cache_budget > 0:
+        self.percentage = a.cache_prune_type == "percentage"
+        if self.percentage:
+            from vllm_paged_compression_amd.page_evict_kv_util import percentage_pruned_prompt
+            if a.evict_freq < 1:
+                raise SystemExit("--cache-prune-type percentage needs --evict-freq >= 1")
+            self.cfg = PagedEvictConfig(not a.evict_prefill, "percentage", "streamingLLM", 0, -1,
+                                        evict_freq=a.evict_freq, num_block_merge=a.num_block_merge,
+                                        prompt_evict_method=a.prompt_evict_method,
+                                        decode_evict_method=a.decode_evict_method)
+            # "budget" here = tokens of the prompt that stay (sizes the CPU baseline's kv length)
+            self.budget = percentage_pruned_prompt(a.input_len, a.block_size, a.evict_freq, 1,
+                                                   a.num_block_merge)[1]
+        elif a.evict > 0 or a.cache_budget > 0:
             self.budget = a.cache_budget or budget_from_percentage(a.evict, a.input_len, a.block_size)
             self.cfg = PagedEvictConfig(not a.evict_prefill, "budget", method, self.budget, 3)
         self.ccfg = CacheConfigView(a.block_size, self.cfg)
@@ -99,6 +123,8 @@ class Workload:
         B = a.num_prompts
         kept = a.input_len if self.cfg is None else min(a.input_len, self.budget + a.input_len % a.block_size)
         max_kv = (a.input_len + a.output_len) if self.cfg is None else kept + a.block_size + 1
+        if self.percentage:
+            max_kv = self.budget + a.output_len + a.block_size
         self.blocks_per_seq = -(-max_kv // a.block_size) + 1
         self.blocks_per_seq_full = -(-(a.input_len + a.output_len) // a.block_size)
         self.num_blocks = B * self.blocks_per_seq + 8
@@ -107,7 +133,8 @@ class Workload:
         self.impls = [PagedEvictBackend.get_impl_cls()(
             self.Hq, self.D, self.D ** -0.5, self.Hkv, None, None, "auto", None, None,
             cache_config=self.ccfg, prefix=f"model.layers.{i}.self_attn.attn",
-            prompt_evict_method=a.prompt_evict_method if self.cfg is not None else None,
+            prompt_evict_method=(a.prompt_evict_method
+                                 if self.cfg is not None and not self.percentage else None),
             tp_group=tp_group, total_num_kv_heads=a.num_kv_heads,
             kv_head_owner=tp_rank % max(1, tp_size // a.num_kv_heads) == 0,
             max_num_seqs=B, max_blocks_per_seq=4 * self.blocks_per_seq_full)
@@ -159,6 +186,20 @@ class Workload:
             e_ev.record()
             self.timed.append((s_ev, e_ev, decode_bytes, len(self.impls) - 1))
 
+    def _evicted_now(self, L, kv_len) -> int:
+        """Tokens that leave the attention view at the decode step whose logical length is L
+        (the kv-length adjustment of model_runner.py:538-543; every request of the batch has the
+        same lengths)."""
+        if self.cfg is None:
+            return 0
+        bs = self.bs
+        if self.percentage:
+            from vllm_paged_compression_amd.page_evict_kv_util import percentage_decode_trigger
+            return ((self.cfg.num_block_merge - 1) * bs
+                    if percentage_decode_trigger(self.cfg, L, int(kv_len), bs) else 0)
+        trig = self.cfg.evict_method != "inverse_key_l2" and L > self.budget and L % bs == 0
+        return bs if trig else 0
+
     # ---- one generation ---------------------------------------------------------------------
     def generate(self):
         if self.a.per_request_scheduler:
@@ -189,9 +230,7 @@ class Workload:
         for _ in range(a.output_len):
             batch = sched.schedule_decode(rids)
             L += 1
-            trig = self.cfg is not None and self.cfg.evict_method != "inverse_key_l2" \
-                and L > self.budget and L % bs == 0
-            kv_adj = batch.kv_lens - (bs if trig else 0)     # model_runner.py:538-543
+            kv_adj = batch.kv_lens - self._evicted_now(L, batch.kv_lens[0])
             meta = self._builder([]).build_decode_batch(batch, kv_adj)
             nbytes = int((2 * kv_adj * self.Hkv * self.D * es + -(-kv_adj // bs) * 4).sum()) \
                 + 2 * B * self.Hq * self.D * es
@@ -228,11 +267,10 @@ class Workload:
         for _ in range(a.output_len):
             tables, kv_lens = sched.schedule_decode(rids)
             L += 1
-            trig = self.cfg is not None and self.cfg.evict_method != "inverse_key_l2" \
-                and L > self.budget and L % bs == 0
+            drop = self._evicted_now(L, kv_lens[0])
             inter, kv_adj = [], []
             for i in range(B):
-                kvl = kv_lens[i] - (bs if trig else 0)
+                kvl = kv_lens[i] - drop
                 kv_adj.append(kvl)
                 inter.append(SimpleNamespace(request_id=rids[i], is_prompt=False,
                                              block_tables={i: tables[i]}, seq_kv_lens={i: kvl},
@@ -321,8 +359,10 @@ def workload_name(a, wl) -> str:
     return (f"Llama-3-8B attention geometry (Hq {a.num_heads}, Hkv {a.num_kv_heads}, D "
             f"{a.head_size}, {a.layers} layers), block {a.block_size}, {a.num_prompts} "
             f"requests {a.input_len}->{a.output_len}, "
-            + (f"{'budget ' + str(wl.budget)} ({a.evict:.0%} eviction), prompt "
-               f"{a.prompt_evict_method} / decode {a.decode_evict_method}"
+            + ((f"percentage prune type, evict-freq {a.evict_freq}, num-block-merge "
+                f"{a.num_block_merge} ({wl.budget} prompt tokens kept)" if wl.percentage else
+                f"{'budget ' + str(wl.budget)} ({a.evict:.0%} eviction)")
+               + f", prompt {a.prompt_evict_method} / decode {a.decode_evict_method}"
                if wl.cfg is not None else "no eviction"))
 
 
@@ -433,7 +473,8 @@ def main():
             "oproj_allreduce": bool(wl.allreduce), **kv},
     }
     main_budget = wl.budget
-    if a.alt_evict > 0 and a.cache_budget == 0 and abs(a.alt_evict - a.evict) > 1e-9:
+    if a.alt_evict > 0 and a.cache_budget == 0 and a.cache_prune_type == "budget" \
+            and abs(a.alt_evict - a.evict) > 1e-9:
         # the same job at the metric's other eviction fraction (outside the timed region above)
         import copy
         a2 = copy.copy(a)
