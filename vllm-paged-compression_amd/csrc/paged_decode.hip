@@ -427,11 +427,16 @@ static int env_int(const char* name, int dflt) {
 }
 
 // Number of KV splits.  A split costs a second (merge) launch and a round trip of the partial
-// results, about 3 us, so it only pays when the workgroups are few AND long: measured on MI355X
-// (4 query heads per KV head, head 128) one split is best for every batch at kv 776, while 8
-// workgroups of kv 4104 run 2.7x faster with 8 splits and one 16k-token sequence 6x faster with
-// 16.  Rule: aim at one workgroup per CU, keep at least 24 block pairs (768 tokens) per split,
-// at most 16 splits.
+// results, about 3 us, so it only pays when the workgroups are few AND long.  Measured on MI355X
+// (4 query heads per KV head, head 128): with at most 64 workgroups a split every 12 block pairs
+// (384 tokens) is best - kv 776: 13.2 -> 12.1 us for one sequence, 14.3 -> 13.6 us for 8;
+// kv 2056: 18.7 -> 13.7 us; kv 4104: 17.7 -> 16.2 us - while 128 workgroups of kv 776 lose
+// (15.4 -> 16.0 us) and want 24 pairs per split; 8 workgroups of kv 4104 run 2.7x faster with 8
+// splits and one 16k-token sequence 6x faster with 16.  An in-launch merge by the last workgroup
+// to arrive was measured too: device-scope fences cost more than the merge launch, and with
+// write-through partials it still loses to it (kv 4104, one sequence: 20.4 vs 16.2 us).
+// Rule: aim at one workgroup per CU, at least 12 pairs per split while the chip is less than a
+// quarter full, 24 beyond, at most 16 splits.
 static int choose_splits(int num_seqs, int num_kv_heads, int max_seq_len) {
   const int forced = env_int("PE_DECODE_SPLITS", 0);
   const int n_pairs = (max_seq_len + 31) / 32;
@@ -441,11 +446,13 @@ static int choose_splits(int num_seqs, int num_kv_heads, int max_seq_len) {
     if (max_splits > 64) max_splits = 64;
     return forced < max_splits ? forced : max_splits;
   }
-  int max_splits = n_pairs / 24;
-  if (max_splits < 1) max_splits = 1;
-  if (max_splits > 16) max_splits = 16;
+  static const int min_pairs_env = env_int("PE_DEC_SPLIT_MIN_PAIRS", 0);
   const int64_t wgs = (int64_t)num_seqs * num_kv_heads;
   const int64_t target = 256;  // one workgroup per CU
+  const int min_pairs = min_pairs_env > 0 ? min_pairs_env : (wgs * 4 <= target ? 12 : 24);
+  int max_splits = n_pairs / min_pairs;
+  if (max_splits < 1) max_splits = 1;
+  if (max_splits > 16) max_splits = 16;
   int splits = (int)(target / wgs);
   if (splits < 1) splits = 1;
   if (splits > max_splits) splits = max_splits;
