@@ -31,9 +31,11 @@ def variant(name, text):
             "const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[sub][n][r], scale_log2e, -m_new));",
             "const float p = s[sub][n][r];")
         text = text.replace("if (__builtin_amdgcn_ballot_w64(m_new > m_run[n]) != 0) {", "if (m_new > 1e30f) {")
-    if name == "nopv":
-        text = text.replace("acc[dt][0] = TR::mfma16(vf, pf[0][k2], acc[dt][0]);", "acc[dt][0][0] += vf[0] + pf[0][k2][0];")
-        text = text.replace("acc[dt][1] = TR::mfma16(vf, pf[1][k2], acc[dt][1]);", "acc[dt][1][0] += vf[1] + pf[1][k2][1];")
+    if name in ("nopv", "nopv_novalu"):
+        text = text.replace("for (int n = 0; n < NR; ++n) acc[dt][n] = TR::mfma16(vf, pf[n][k2], acc[dt][n]);",
+                            "for (int n = 0; n < NR; ++n) acc[dt][n][0] += (float)vf[n] + (float)pf[n][k2][dt & 7];")
+    if name == "nopv_novalu":
+        text = variant("novalu", text)
     return text
 
 

@@ -48,6 +48,20 @@ __device__ __forceinline__ int swz_off_v(int row, int chunk) {
 
 // NR: 16-row query tiles per wave; WAVES: waves per workgroup (query rows per workgroup =
 // 16 * NR * WAVES); WPE: waves per SIMD the register budget is cut for.
+// max over the four lanes l, l^16, l^32, l^48 with the row-swap permutes (VALU, no LDS round
+// trip as a ds_bpermute shuffle would take): v_permlane32_swap exchanges the upper half of its
+// first operand with the lower half of its second, v_permlane16_swap the odd 16-lane rows of the
+// first with the even rows of the second; with both operands equal the two results hold, in
+// every lane, the lane's own value and its partner's.
+__device__ __forceinline__ float max_xor_16_32(float x) {
+  unsigned u = __float_as_uint(x);
+  auto a = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  x = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  u = __float_as_uint(x);
+  auto b = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
 template <typename T, int D, int NR, int WAVES, int WPE>
 __global__ __launch_bounds__(WAVES * 64, WPE) void prefill_mfma_kernel(
     T* __restrict__ out, const T* __restrict__ q, const T* __restrict__ k,
@@ -192,18 +206,30 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void prefill_mfma_kernel(
     const char* kt = k_tile(buf);
     const char* vt = v_tile(buf);
     // ---- S^T = K.Q^T ---------------------------------------------------------------
+    // The K fragments of row group sub+1 are requested before the MFMAs of group sub are issued
+    // (the scheduling fences keep that order), so that an MFMA waits for reads issued a whole
+    // group earlier instead of for the read right in front of it.
     f32x4 s[4][NR];
+    vec8 kf[2][KS];
+    auto load_k = [&](int sub, vec8* dst) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        dst[ks] = __builtin_bit_cast(
+            vec8, *reinterpret_cast<const u32x4*>(kt + swz_off<D>(sub * 16 + c, 4 * ks + g)));
+    };
+    load_k(0, kf[0]);
 #pragma unroll
     for (int sub = 0; sub < 4; ++sub) {
+      if (sub + 1 < 4) load_k(sub + 1, kf[(sub + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int n = 0; n < NR; ++n) s[sub][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        const vec8 kf = __builtin_bit_cast(
-            vec8, *reinterpret_cast<const u32x4*>(kt + swz_off<D>(sub * 16 + c, 4 * ks + g)));
 #pragma unroll
-        for (int n = 0; n < NR; ++n) s[sub][n] = TR::mfma16(kf, qf[n][ks], s[sub][n]);
+        for (int n = 0; n < NR; ++n) s[sub][n] = TR::mfma16(kf[sub & 1][ks], qf[n][ks], s[sub][n]);
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
     // ---- mask, online softmax (the scale rides in the exponent's fma; maxima are kept in
     //      scaled log2 units, which needs scale > 0 - the launcher guarantees it) ----------
@@ -224,8 +250,7 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void prefill_mfma_kernel(
       for (int sub = 0; sub < 4; ++sub)
 #pragma unroll
         for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[sub][n][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 16));
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      mx = max_xor_16_32(mx);
       const float m_new = fmaxf(m_run[n], mx * scale_log2e);
       if (__builtin_amdgcn_ballot_w64(m_new > m_run[n]) != 0) {  // wave-uniform: some row's max grew
         const float alpha = __builtin_amdgcn_exp2f(m_run[n] - m_new);
