@@ -125,12 +125,20 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void prefill_mfma_kernel(
       qf[n][ks] = __builtin_bit_cast(vec8, *reinterpret_cast<const u32x4*>(qp + 32 * ks));
   }
 
-  float m_run[NR], l_run[NR];
+  // The row sums ride on the matrix pipe: one more MFMA per P fragment with an all-ones A operand
+  // adds the (storage-type rounded) probabilities of a query row over the fragment's 32 keys, in
+  // every lane of the row's column - no vector adds per element, no cross-lane sum at the end,
+  // and numerator and denominator use the same rounded weights.
+  float m_run[NR];
+  f32x4 acc_l[NR];
   f32x4 acc[DT][NR];
+  vec8 ones;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones[j] = (T)1.0f;
 #pragma unroll
   for (int n = 0; n < NR; ++n) {
     m_run[n] = PF_NEG;
-    l_run[n] = 0.f;
+    acc_l[n] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) acc[dt][n] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
@@ -255,21 +263,18 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void prefill_mfma_kernel(
       if (__builtin_amdgcn_ballot_w64(m_new > m_run[n]) != 0) {  // wave-uniform: some row's max grew
         const float alpha = __builtin_amdgcn_exp2f(m_run[n] - m_new);
         m_run[n] = m_new;
-        l_run[n] *= alpha;
+        acc_l[n] *= alpha;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) acc[dt][n] *= alpha;
       }
-      float psum = 0.f;
 #pragma unroll
       for (int sub = 0; sub < 4; ++sub) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[sub][n][r], scale_log2e, -m_new));
-          psum += p;
           pf[n][sub >> 1][(sub & 1) * 4 + r] = (T)p;
         }
       }
-      l_run[n] += psum;
     }
     // ---- O^T += V^T.P^T ------------------------------------------------------------------
     // transposed read: lane i of each 16-lane group addresses row (4g + i/4), columns
@@ -277,6 +282,8 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void prefill_mfma_kernel(
     const int tq = c >> 2, tp = c & 3;
 #pragma unroll
     for (int k2 = 0; k2 < 2; ++k2) {
+#pragma unroll
+      for (int n = 0; n < NR; ++n) acc_l[n] = TR::mfma16(ones, pf[n][k2], acc_l[n]);
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
         const int row_lo = (2 * k2) * 16 + 4 * g + tq;
@@ -331,9 +338,7 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void prefill_mfma_kernel(
   char* o_lds = smem + wave * (WROWS * D * 2);
 #pragma unroll
   for (int n = 0; n < NR; ++n) {
-    float l = l_run[n];
-    l += __shfl_xor(l, 16);
-    l += __shfl_xor(l, 32);
+    const float l = acc_l[n][0];  // every output row of the ones-MFMA holds the column's sum
     const float inv = l > 0.f ? 1.f / l : 0.f;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
