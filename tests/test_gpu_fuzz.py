@@ -15,6 +15,7 @@ pytestmark = pytest.mark.gpu
 BS = 16
 HQ, HKV, D, LAYERS = 8, 2, 64, 2
 BUDGET, TOPK = 128, 3
+FREQ, NBM = 2, 2   # percentage prune type ("pct:<decode method>" cases)
 
 
 def _rand(T, H, g, scale):
@@ -24,7 +25,8 @@ def _rand(T, H, g, scale):
 @pytest.mark.parametrize("vectorised", [False, True])
 @pytest.mark.parametrize("method,seed,evict_before_prefill", [
     ("streamingLLM", 0, False), ("streamingLLM-1", 1, False), ("global", 2, False), ("global", 3, False),
-    ("local", 4, False), ("streamingLLM", 5, True), ("global", 6, True)])
+    ("local", 4, False), ("streamingLLM", 5, True), ("global", 6, True),
+    ("pct:streamingLLM", 7, False), ("pct:value_l2", 8, False), ("pct:value_l2", 9, True)])
 def test_continuous_batching_fuzz(oracle, method, seed, evict_before_prefill, vectorised):
     from vllm_paged_compression_amd.backend import PagedEvictBackend
     from vllm_paged_compression_amd.batch_scheduler import BatchEvictionScheduler
@@ -34,7 +36,13 @@ def test_continuous_batching_fuzz(oracle, method, seed, evict_before_prefill, ve
     rng = random.Random(100 + seed)
     g = torch.Generator().manual_seed(200 + seed)
     nb = 160
-    cfg = PagedEvictConfig(not evict_before_prefill, "budget", method, BUDGET, TOPK)
+    pct = method.startswith("pct:")
+    if pct:
+        method = method[4:]
+        cfg = PagedEvictConfig(not evict_before_prefill, "percentage", "streamingLLM", 0, -1,
+                               evict_freq=FREQ, num_block_merge=NBM, decode_evict_method=method)
+    else:
+        cfg = PagedEvictConfig(not evict_before_prefill, "budget", method, BUDGET, TOPK)
     ccfg = CacheConfigView(BS, cfg)
     impls = [PagedEvictBackend.get_impl_cls()(HQ, D, D ** -0.5, HKV, None, None, "auto", None, None,
                                               cache_config=ccfg, prefix=f"model.layers.{i}.self_attn.attn",
@@ -99,7 +107,11 @@ def test_continuous_batching_fuzz(oracle, method, seed, evict_before_prefill, ve
                 q3, k3, v3 = q.view(T, HQ, D), k.view(T, HKV, D), v.view(T, HKV, D)
                 pk, pv, off = [], [], 0
                 for n in lens:
-                    a, b = oracle.prompt_prune(k3[off:off + n], v3[off:off + n], method, BUDGET, BS)
+                    if pct:
+                        keep = oracle.percentage_keep_indices(n, BS, FREQ, 1, NBM)
+                        a, b = k3[off:off + n][keep], v3[off:off + n][keep]
+                    else:
+                        a, b = oracle.prompt_prune(k3[off:off + n], v3[off:off + n], method, BUDGET, BS)
                     pk.append(a)
                     pv.append(b)
                     off += n
@@ -113,7 +125,7 @@ def test_continuous_batching_fuzz(oracle, method, seed, evict_before_prefill, ve
                                          torch.tensor(slot_expect))
                 assert torch.equal(kv_gpu[li][0].view_as(kc_cpu[li]).cpu(), kc_cpu[li]), (step, li)
                 assert torch.equal(kv_gpu[li][1].view_as(vc_cpu[li]).cpu(), vc_cpu[li]), (step, li)
-                if li == 0 and method in ("global", "local"):
+                if li == 0 and not pct and method in ("global", "local"):
                     for (_, rid, _, _), t in zip(grp, pv):
                         scores[rid] = [oracle.block_score(t[b * BS:(b + 1) * BS].contiguous(), BS, HKV, D, 0)
                                        for b in range(t.shape[0] // BS)]
@@ -125,13 +137,20 @@ def test_continuous_batching_fuzz(oracle, method, seed, evict_before_prefill, ve
             tables, kv_lens = ref_sched.schedule_decode(running)
             batch = vec_sched.schedule_decode(running) if vec_sched is not None else None
             B = len(running)
-            L, kv_adj, tbls = [], [], []
+            L, kv_adj, tbls, merged = [], [], [], []
+            n_rm = NBM - 1 if pct else 1
             for rid in running:
                 sid = seq_of[rid]
                 logical[rid] += 1
                 L.append(logical[rid])
-                kv_adj.append(kv_lens[sid] - (BS if oracle.decode_trigger(logical[rid], BUDGET, BS) else 0))
                 tbls.append(list(tables[sid]))
+                if pct:
+                    first, _, mg = oracle.percentage_decode_blocks(logical[rid], len(tbls[-1]), BS, FREQ,
+                                                                   method, 1, NBM)
+                    merged.append(mg)
+                    kv_adj.append(kv_lens[sid] - (n_rm * BS if first >= 0 else 0))
+                else:
+                    kv_adj.append(kv_lens[sid] - (BS if oracle.decode_trigger(logical[rid], BUDGET, BS) else 0))
             if batch is not None:
                 import numpy as np
                 meta = builder([]).build_decode_batch(batch, np.asarray(kv_adj))
@@ -146,7 +165,10 @@ def test_continuous_batching_fuzz(oracle, method, seed, evict_before_prefill, ve
             slots = [oracle.decode_slot(t, kv_lens[seq_of[r]] - 1, BS) for t, r in zip(tbls, running)]
             assert meta.slot_mapping.cpu().tolist() == slots
             zero_slots = []
-            if method in ("streamingLLM", "streamingLLM-1"):
+            if pct:
+                rmv = [oracle.percentage_decode_blocks(L[i], len(tbls[i]), BS, FREQ, method, 1, NBM)[0]
+                       for i in range(B)]
+            elif method in ("streamingLLM", "streamingLLM-1"):
                 rmv, zero_slots = oracle.decode_streaming(L, tbls, BUDGET, BS, method)
             else:
                 rmv = []
@@ -161,7 +183,10 @@ def test_continuous_batching_fuzz(oracle, method, seed, evict_before_prefill, ve
             for i, t in enumerate(tbls):
                 bt[i, :len(t)] = torch.tensor(t)
             use_tables = bt
-            if any(r >= 0 for r in rmv):
+            if pct and any(r >= 0 for r in rmv):
+                use_tables = oracle.table_remove_range(
+                    bt, rmv, n_rm, max(len(t) - (n_rm if r >= 0 else 0) for t, r in zip(tbls, rmv)))
+            elif any(r >= 0 for r in rmv):
                 use_tables = oracle.compact_block_tables(
                     bt, rmv, out_width=oracle.surviving_width([len(t) for t in tbls], rmv))
             for li in range(LAYERS):
@@ -172,6 +197,9 @@ def test_continuous_batching_fuzz(oracle, method, seed, evict_before_prefill, ve
                 if zero_slots:
                     z = torch.zeros(len(zero_slots), HKV, D, dtype=torch.bfloat16)
                     oracle.reshape_and_cache(z, z, kc_cpu[li], vc_cpu[li], torch.tensor(zero_slots))
+                for i, mg in enumerate(merged):
+                    if mg is not None:
+                        oracle.merge_blocks_in_cache(kc_cpu[li], vc_cpu[li], tbls[i][mg[0]:mg[1]])
                 assert torch.equal(kv_gpu[li][0].view_as(kc_cpu[li]).cpu(), kc_cpu[li]), (step, li)
                 assert torch.equal(kv_gpu[li][1].view_as(vc_cpu[li]).cpu(), vc_cpu[li]), (step, li)
                 ref = oracle.paged_attention(q.view(B, HQ, D), kc_cpu[li], vc_cpu[li], use_tables,
@@ -188,7 +216,7 @@ def test_continuous_batching_fuzz(oracle, method, seed, evict_before_prefill, ve
                 vec_sched.commit(got)
             for i, rid in enumerate(running):
                 if rmv[i] >= 0:
-                    del tbls[i][rmv[i]]
+                    del tbls[i][rmv[i]:rmv[i] + n_rm]
                 assert bm.get_block_table(seq_of[rid]) == tbls[i]
                 if vec_sched is not None:
                     assert vec_sched.get_block_table(rid) == tbls[i]
