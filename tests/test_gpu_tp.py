@@ -35,9 +35,10 @@ def _inputs(T, g):
     return q, k, v
 
 
-def run_trace(rank, world, group):
+def run_trace(rank, world, group, mode="budget"):
     """One generation on this rank's head shard; returns ([victims per step], [output per step
-    and layer, all on the CPU], final block tables)."""
+    and layer, all on the CPU], final block tables).  mode "budget": value_l2 block eviction;
+    "percentage": the README-era type with the per-head value_l2 block merge at decode."""
     sys.path.insert(0, ROOT)
     from vllm_paged_compression_amd import parallel
     from vllm_paged_compression_amd.backend import PagedEvictBackend
@@ -45,7 +46,12 @@ def run_trace(rank, world, group):
     from vllm_paged_compression_amd.config import CacheConfigView, PagedEvictConfig
     dev = torch.device("cuda:0")
     sh = parallel.shard_heads(HQ, HKV, world, rank)
-    cfg = PagedEvictConfig(True, "budget", "global", BUDGET, 3)
+    from vllm_paged_compression_amd.page_evict_kv_util import percentage_decode_trigger
+    if mode == "percentage":
+        cfg = PagedEvictConfig(True, "percentage", "streamingLLM", 0, -1, evict_freq=2,
+                               num_block_merge=2, decode_evict_method="value_l2")
+    else:
+        cfg = PagedEvictConfig(True, "budget", "global", BUDGET, 3)
     ccfg = CacheConfigView(BS, cfg)
     nb = 96
     impls = [PagedEvictBackend.get_impl_cls()(
@@ -93,7 +99,10 @@ def run_trace(rank, world, group):
             sid = seq_of[rid]
             seq_len[rid] += 1
             L = seq_len[rid]
-            kvl = kv_lens[sid] - (BS if (L > BUDGET and L % BS == 0) else 0)
+            if mode == "percentage":
+                kvl = kv_lens[sid] - (BS if percentage_decode_trigger(cfg, L, kv_lens[sid], BS) else 0)
+            else:
+                kvl = kv_lens[sid] - (BS if (L > BUDGET and L % BS == 0) else 0)
             logical.append(L)
             inter.append(SimpleNamespace(request_id=rid, is_prompt=False,
                                          block_tables={sid: list(tables[sid])}, seq_kv_lens={sid: kvl},
@@ -110,13 +119,13 @@ def run_trace(rank, world, group):
     return victims, outputs, final_tables
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, mode="budget"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        victims, outputs, tables = run_trace(rank, world, dist.group.WORLD)
+        victims, outputs, tables = run_trace(rank, world, dist.group.WORLD, mode)
         q.put((rank, "ok", victims, [o.float().numpy() for o in outputs], tables))
     except Exception as e:  # pragma: no cover
         import traceback
@@ -125,14 +134,15 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_two_rank_value_l2_eviction_matches_single_rank():
+@pytest.mark.parametrize("mode", ["budget", "percentage"])
+def test_two_rank_value_l2_eviction_matches_single_rank(mode):
     import torch.multiprocessing as mp
-    ref_victims, ref_out, ref_tables = run_trace(0, 1, None)
+    ref_victims, ref_out, ref_tables = run_trace(0, 1, None, mode)
     assert sum(len(v) for v in ref_victims) >= 3
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, mode)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=110) for _ in procs)
