@@ -188,13 +188,17 @@ int pe_prompt_keep_index_streaming(int32_t* src_index, const int32_t* cu_q,
  * compat_q2 != 0 lays the index out the way the reference's `middle[mask].view(-1,H,D)`
  * re-packs rows across heads (kvcache_prunner.py:251-252); then each entry is
  * row*num_kv_heads + head of the source (token, head) pair.
+ * cache_budget == 0 selects the geometry of the "percentage" prune type
+ * (vllm/attention/kvcache_prunner_old.py:201-262): the last tail_blocks (= num_block_merge)
+ * blocks and the remainder stay, and request r loses as many middle tokens as its length
+ * exceeds its kept length; tail_blocks is ignored otherwise (the budget type keeps one block).
  * total_q = number of key/value rows (= cu_q[num_seqs]).
  * workspace: pe_prompt_token_select_workspace_bytes(total_q, num_kv_heads) bytes. */
 int64_t pe_prompt_token_select_workspace_bytes(int64_t total_q, int num_kv_heads);
 int pe_prompt_token_select(int32_t* src_index, const void* key, const void* value,
                            const int32_t* cu_q, const int32_t* cu_kept, int num_seqs,
                            int64_t total_q, int cache_budget, int block_size, int method, int compat_q2,
-                           int64_t key_stride, int64_t value_stride, int num_kv_heads,
+                           int tail_blocks, int64_t key_stride, int64_t value_stride, int num_kv_heads,
                            int head_size, int dtype, void* workspace,
                            int64_t workspace_bytes, void* stream);
 

@@ -417,6 +417,37 @@ def percentage_keep_indices(q_len: int, block_size: int, evict_freq: int, initia
     return list(range(0, end_first)) + list(range(end_first + n_prune, q_len))
 
 
+def percentage_prompt_prune(keys: torch.Tensor, values: torch.Tensor, method: str, block_size: int,
+                            evict_freq: int, initial_blocks: int = 1, num_block_merge: int = 2,
+                            compat_q2: bool = False):
+    """prune_prompt of the percentage type, kvcache_prunner_old.py:137-262: streamingLLM drops
+    the oldest middle tokens, "value_l2" / "inverse_key_l2" the lowest-score ones per head
+    (compat_q2: the reference's cross-head re-packing ``middle[mask].view(-1, H, D)``, :246-247)."""
+    L, H, D = keys.shape
+    end_first, end_mid, n_prune = percentage_prompt_slices(L, block_size, evict_freq, initial_blocks,
+                                                           num_block_merge)
+    if n_prune == 0:
+        return keys, values
+    if method == "streamingLLM":
+        idx = torch.tensor(percentage_keep_indices(L, block_size, evict_freq, initial_blocks,
+                                                   num_block_merge), dtype=torch.long)
+        return keys[idx], values[idx]
+    mk, mv = keys[end_first:end_mid], values[end_first:end_mid]
+    keep = topk_keep_mask(token_scores(mk, mv, "global" if method == "value_l2" else method), n_prune)
+    if compat_q2:
+        pk, pv = mk[keep].view(-1, H, D), mv[keep].view(-1, H, D)
+    else:
+        n_keep = mk.shape[0] - n_prune
+        pk = torch.empty((n_keep, H, D), dtype=keys.dtype)
+        pv = torch.empty((n_keep, H, D), dtype=keys.dtype)
+        for h in range(H):
+            sel = keep[:, h].nonzero().flatten()
+            pk[:, h] = mk[sel, h]
+            pv[:, h] = mv[sel, h]
+    return (torch.cat([keys[:end_first], pk, keys[end_mid:]], dim=0),
+            torch.cat([values[:end_first], pv, values[end_mid:]], dim=0))
+
+
 def percentage_decode_blocks(seq_len: int, table_len: int, block_size: int, evict_freq: int,
                              method: str, initial_blocks: int = 1, num_block_merge: int = 2):
     """Decode step of the percentage type: (first freed table column or -1, columns freed,

@@ -240,6 +240,23 @@ def main():
     with open(os.path.join(HERE, "percentage_tables.json"), "w") as f:
         json.dump(pct, f)
 
+    # token-level prompt prune of the same mode (value_l2 / inverse_key_l2), tie-free f32 inputs
+    out = {}
+    case = 0
+    for mi, method in enumerate(("value_l2", "inverse_key_l2")):
+        for (L, freq, bs, nbm, H, D) in [(100, 2, 16, 2, 4, 16), (150, 4, 16, 2, 2, 16), (130, 3, 16, 3, 3, 8),
+                                         (200, 2, 8, 2, 2, 8)]:
+            g = torch.Generator().manual_seed(7000 + case)
+            k = torch.rand(L, H, D, generator=g) * 2 - 1
+            v = torch.rand(L, H, D, generator=g) * 2 - 1
+            p = old_pruner(method, "streamingLLM", bs, freq, 1, nbm)
+            pk, pv = p.prune_prompt(k, v)
+            out[f"c{case}_meta"] = np.array([L, freq, bs, nbm, H, D, mi])
+            out[f"c{case}_k"], out[f"c{case}_v"] = bits(k), bits(v)
+            out[f"c{case}_pk"], out[f"c{case}_pv"] = bits(pk), bits(pv)
+            case += 1
+    np.savez_compressed(os.path.join(HERE, "percentage_prompt_topk.npz"), **out)
+
     # decode-time merge (prune_oldest_block): tie-free f32 inputs, the reference's output rows
     # (kept (token, head) rows re-packed across heads, keys also returned as values - both are
     # properties of the reference's code, kvcache_prunner_old.py:312-313)

@@ -23,10 +23,10 @@ def ops():
     return ops
 
 
-def _cfg(freq, nbm=2, decode="streamingLLM", disable_evict_prefill=True):
+def _cfg(freq, nbm=2, decode="streamingLLM", disable_evict_prefill=True, prompt="streamingLLM"):
     from vllm_paged_compression_amd.config import PagedEvictConfig
-    return PagedEvictConfig(disable_evict_prefill, "percentage", "streamingLLM", 0, -1,
-                            evict_freq=freq, num_block_merge=nbm, decode_evict_method=decode)
+    return PagedEvictConfig(disable_evict_prefill, "percentage", prompt, 0, -1, evict_freq=freq,
+                            num_block_merge=nbm, decode_evict_method=decode)
 
 
 def test_keep_index_percentage_golden(ops):
@@ -61,6 +61,45 @@ def test_pruner_percentage_prompt(ops, oracle, freq):
         off += L
     assert kept == [len(oracle.percentage_keep_indices(L, BS, freq)) for L in lens]
     assert torch.equal(pk.cpu(), k[rows]) and torch.equal(pv.cpu(), v[rows])
+
+
+@pytest.mark.parametrize("compat", [True, False])
+def test_pruner_percentage_prompt_topk_golden(ops, oracle, compat):
+    """Token-level prompt prune of the percentage type: the reference's outputs with its
+    cross-head re-packing (compat), the oracle's per-head form otherwise."""
+    from vllm_paged_compression_amd.pruner import KVCachePruner
+    z = np.load(os.path.join(GOLDEN, "percentage_prompt_topk.npz"))
+    n = len([k for k in z.files if k.endswith("_meta")])
+    for c in range(n):
+        L, freq, bs, nbm, H, D, mi = [int(v) for v in z[f"c{c}_meta"]]
+        method = ("value_l2", "inverse_key_l2")[mi]
+        k, v = from_bits(z[f"c{c}_k"], 0), from_bits(z[f"c{c}_v"], 0)
+        p = KVCachePruner("percentage", method, bs, 0, 1, evict_freq=freq, num_block_merge=nbm,
+                          decode_evict_method="streamingLLM", cross_head_compat=compat)
+        pk, pv = p.prune_prompt(k.cuda(), v.cuda())
+        if compat:
+            ek, ev = from_bits(z[f"c{c}_pk"], 0), from_bits(z[f"c{c}_pv"], 0)
+        else:
+            ek, ev = oracle.percentage_prompt_prune(k, v, method, bs, freq, 1, nbm)
+        assert torch.equal(pk.cpu(), ek) and torch.equal(pv.cpu(), ev), (c, method)
+    # a batch of prompts, some too short to prune, 16-bit storage
+    g = torch.Generator().manual_seed(3)
+    lens = [300, 40, 130]
+    k = torch.rand(sum(lens), 2, 64, generator=g).to(torch.bfloat16)
+    v = torch.rand(sum(lens), 2, 64, generator=g).to(torch.bfloat16)
+    p = KVCachePruner("percentage", "value_l2", 16, 0, 1, evict_freq=2, decode_evict_method="value_l2")
+    pk, pv, kept = p.prune_prompts_batch(k.cuda(), v.cuda(), lens)
+    off, ek, ev = 0, [], []
+    for L in lens:
+        a, b = oracle.percentage_prompt_prune(k[off:off + L], v[off:off + L], "value_l2", 16, 2)
+        ek.append(a)
+        ev.append(b)
+        off += L
+    assert kept == [t.shape[0] for t in ek]
+    # 16-bit scores tie: oracle and kernel drop the lowest token first
+    assert pk.shape[0] == sum(kept)
+    gk, gv = pk.cpu(), pv.cpu()
+    assert torch.equal(gk, torch.cat(ek)) and torch.equal(gv, torch.cat(ev))
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
@@ -150,11 +189,14 @@ def _mk(T, Hq, Hkv, D, g):
     return q, k, v
 
 
-@pytest.mark.parametrize("decode_method,nbm,freq,batched", [
-    ("streamingLLM", 2, 2, False), ("value_l2", 2, 2, False), ("value_l2", 3, 1, False),
-    ("value_l2", 2, 2, True), ("streamingLLM", 3, 2, True)])
+@pytest.mark.parametrize("decode_method,nbm,freq,batched,prompt_method", [
+    ("streamingLLM", 2, 2, False, "streamingLLM"), ("value_l2", 2, 2, False, "streamingLLM"),
+    ("value_l2", 3, 1, False, "streamingLLM"), ("value_l2", 2, 2, True, "streamingLLM"),
+    ("streamingLLM", 3, 2, True, "streamingLLM"), ("value_l2", 2, 2, False, "value_l2"),
+    ("value_l2", 2, 4, True, "inverse_key_l2")])
 @pytest.mark.parametrize("disable_evict_prefill", [True, False])
-def test_backend_percentage_trace(oracle, decode_method, nbm, freq, batched, disable_evict_prefill):
+def test_backend_percentage_trace(oracle, decode_method, nbm, freq, batched, prompt_method,
+                                  disable_evict_prefill):
     """Builder -> forward over two layers -> get_rmv_block_idx -> scheduler commit, every step
     against a CPU walk: block tables and freed columns identical, KV caches byte-identical
     (merged blocks included), attention within the kernel-test tolerance."""
@@ -166,7 +208,7 @@ def test_backend_percentage_trace(oracle, decode_method, nbm, freq, batched, dis
     g = torch.Generator().manual_seed(17 + nbm)
     Hq, Hkv, D, L_layers, nb = 8, 2, 128, 2, 96
     n_decode = 70
-    cfg = _cfg(freq, nbm, decode_method, disable_evict_prefill)
+    cfg = _cfg(freq, nbm, decode_method, disable_evict_prefill, prompt_method)
     cache_cfg = CacheConfigView(BS, cfg)
     impls = [PagedEvictBackend.get_impl_cls()(
         Hq, D, D ** -0.5, Hkv, None, None, "auto", None, None, cache_config=cache_cfg,
@@ -212,7 +254,16 @@ def test_backend_percentage_trace(oracle, decode_method, nbm, freq, batched, dis
         q, k, v = _mk(T, Hq, Hkv, D, g)
         out = impls[li].forward(q.cuda(), k.cuda(), v.cuda(), kv_gpu[li], meta)
         q3, k3, v3 = q.view(T, Hq, D), k.view(T, Hkv, D), v.view(T, Hkv, D)
-        pk, pv = k3[rows], v3[rows]
+        pk, pv, off = [], [], 0
+        for n in lens:
+            a, b = oracle.percentage_prompt_prune(k3[off:off + n], v3[off:off + n], prompt_method, BS,
+                                                  freq, 1, nbm)
+            pk.append(a)
+            pv.append(b)
+            off += n
+        pk, pv = torch.cat(pk), torch.cat(pv)
+        if prompt_method == "streamingLLM":
+            assert torch.equal(pk, k3[rows]) and torch.equal(pv, v3[rows])
         if disable_evict_prefill:
             ref = oracle.prefill_attention(q3.float(), k3.float(), v3.float(), lens, lens, D ** -0.5)
         else:
@@ -280,4 +331,4 @@ def test_backend_percentage_trace(oracle, decode_method, nbm, freq, batched, dis
         for i in range(3):
             assert table_of(i) == after[i]
             assert kvlen_of(i) == kv_adj[i]
-    assert n_prunes >= 4
+    assert n_prunes >= 3

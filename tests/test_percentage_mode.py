@@ -70,6 +70,23 @@ def test_oracle_merge_golden(oracle):
         assert torch.equal(pk, from_bits(z[f"c{c}_pv"], 0)), c
 
 
+def test_oracle_prompt_topk_golden(oracle):
+    """Token-level prompt prune of the percentage type against the reference's old pruner
+    (cross-head re-packing as it does it; the per-head form keeps the same rows per head)."""
+    z = np.load(os.path.join(GOLDEN, "percentage_prompt_topk.npz"))
+    n = len([k for k in z.files if k.endswith("_meta")])
+    assert n >= 8
+    for c in range(n):
+        L, freq, bs, nbm, H, D, mi = [int(v) for v in z[f"c{c}_meta"]]
+        method = ("value_l2", "inverse_key_l2")[mi]
+        k, v = from_bits(z[f"c{c}_k"], 0), from_bits(z[f"c{c}_v"], 0)
+        pk, pv = oracle.percentage_prompt_prune(k, v, method, bs, freq, 1, nbm, compat_q2=True)
+        assert torch.equal(pk, from_bits(z[f"c{c}_pk"], 0)), c
+        assert torch.equal(pv, from_bits(z[f"c{c}_pv"], 0)), c
+        ik, iv = oracle.percentage_prompt_prune(k, v, method, bs, freq, 1, nbm)
+        assert ik.shape == pk.shape == (len(oracle.percentage_keep_indices(L, bs, freq, 1, nbm)), H, D)
+
+
 def test_oracle_merge_in_cache(oracle):
     g = torch.Generator().manual_seed(5)
     nb, H, D, bs, x = 6, 2, 16, 16, 8
@@ -131,8 +148,10 @@ def test_config_percentage_validation():
         PagedEvictConfig(True, "percentage", "streamingLLM", 0, -1, evict_freq=2,
                          decode_evict_method="global")
     with pytest.raises(ValueError):
-        PagedEvictConfig(True, "percentage", "value_l2", 0, -1, evict_freq=2,
+        PagedEvictConfig(True, "percentage", "key_l1", 0, -1, evict_freq=2,
                          decode_evict_method="value_l2")
+    assert PagedEvictConfig(True, "percentage", "value_l2", 0, -1, evict_freq=2,
+                            decode_evict_method="value_l2").prompt_evict_method == "value_l2"
 
 
 @pytest.mark.parametrize("method", ["streamingLLM", "value_l2"])

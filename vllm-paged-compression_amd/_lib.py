@@ -38,7 +38,7 @@ SIGNATURES = {
                                                c_void_p]),
     "pe_prompt_token_select_workspace_bytes": (c_int64, [c_int64, c_int]),
     "pe_prompt_token_select": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                                       c_int64, c_int, c_int, c_int, c_int, c_int64, c_int64,
+                                       c_int64, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64,
                                        c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
     "pe_block_score_value_l2": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64,
                                         c_int, c_int, c_int, c_int, c_void_p]),

@@ -458,7 +458,8 @@ class PagedEvictImpl(_ImplBase):
             if pec.cache_prune_type == "percentage":
                 self.kv_cache_pruner = KVCachePruner(
                     "percentage", pec.prompt_evict_method, self.cache_config.block_size,
-                    pec.cache_budget, pec.initial_blocks, evict_freq=pec.evict_freq,
+                    pec.cache_budget, pec.initial_blocks,
+                    cross_head_compat=self.compat.prompt_prune_cross_head, evict_freq=pec.evict_freq,
                     num_block_merge=pec.num_block_merge,
                     decode_evict_method=pec.decode_evict_method)
             else:

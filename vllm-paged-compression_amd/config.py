@@ -15,7 +15,7 @@ logger = logging.getLogger(__name__)
 
 EVICT_METHODS = ("streamingLLM", "streamingLLM-1", "inverse_key_l2", "local", "global")
 # methods of the "percentage" prune type (README-era --prompt-evict-method / --decode-evict-method)
-PERCENTAGE_PROMPT_METHODS = ("streamingLLM",)
+PERCENTAGE_PROMPT_METHODS = ("streamingLLM", "value_l2", "inverse_key_l2")
 PERCENTAGE_DECODE_METHODS = ("streamingLLM", "value_l2")
 
 
@@ -36,7 +36,8 @@ class PagedEvictConfig:
                            (whole blocks) and a decode step prunes every evict_freq blocks
     num_block_merge:       blocks a decode prune works on: num_block_merge-1 of them are freed
     prompt_evict_method / decode_evict_method: the two method flags of that era
-                           ("streamingLLM"; "streamingLLM" or "value_l2"); default evict_method
+                           (prompt: "streamingLLM", "value_l2", "inverse_key_l2"; decode:
+                           "streamingLLM", "value_l2"); default evict_method
     """
 
     def __init__(self, disable_evict_prefill: bool, cache_prune_type: str, evict_method: str,

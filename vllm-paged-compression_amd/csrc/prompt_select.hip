@@ -74,8 +74,12 @@ struct SliceGeom {
   int q0, L, k0, mid, n_prune, end_mid;
 };
 
+// budget > 0: the budget prune type (first block, budgeted middle, last block + remainder).
+// budget == 0: the percentage prune type - the last tail_blocks blocks (+ remainder) stay and the
+// number of pruned middle tokens is the request's length minus its kept length
+// (kvcache_prunner_old.py:203-233).
 __device__ __forceinline__ SliceGeom slice_geom(const int32_t* cu_q, const int32_t* cu_kept, int r,
-                                                int budget, int bs) {
+                                                int budget, int bs, int tail_blocks) {
   SliceGeom g;
   g.q0 = cu_q[r];
   g.L = cu_q[r + 1] - g.q0;
@@ -83,7 +87,14 @@ __device__ __forceinline__ SliceGeom slice_geom(const int32_t* cu_q, const int32
   g.mid = 0;
   g.n_prune = 0;
   g.end_mid = g.L;
-  if (g.L > budget) {
+  if (budget == 0) {
+    const int n_prune = g.L - (cu_kept[r + 1] - g.k0);
+    if (n_prune > 0) {
+      g.end_mid = g.L - tail_blocks * bs - g.L % bs;
+      g.mid = g.end_mid - bs;
+      g.n_prune = n_prune;
+    }
+  } else if (g.L > budget) {
     const int rem = g.L % bs;
     g.end_mid = g.L - bs - rem;
     g.mid = g.end_mid - bs;
@@ -96,13 +107,14 @@ __device__ __forceinline__ SliceGeom slice_geom(const int32_t* cu_q, const int32
 __global__ __launch_bounds__(SEL_THREADS) void token_select_kernel(
     int32_t* __restrict__ src_index, uint8_t* __restrict__ keep_flags,
     const float* __restrict__ scores, const int32_t* __restrict__ cu_q,
-    const int32_t* __restrict__ cu_kept, int budget, int bs, int num_heads, int compat_q2) {
+    const int32_t* __restrict__ cu_kept, int budget, int bs, int num_heads, int compat_q2,
+    int tail_blocks) {
   __shared__ int hist[256];
   __shared__ int wave_tot[4];
   __shared__ int sh_bin, sh_k;
   const int h = blockIdx.x, r = blockIdx.y;
   const int tid = threadIdx.x;
-  const SliceGeom g = slice_geom(cu_q, cu_kept, r, budget, bs);
+  const SliceGeom g = slice_geom(cu_q, cu_kept, r, budget, bs, tail_blocks);
   const int H = num_heads;
 
   if (g.n_prune == 0) {
@@ -182,11 +194,11 @@ __global__ __launch_bounds__(SEL_THREADS) void token_select_kernel(
 __global__ __launch_bounds__(SEL_THREADS) void token_index_compat_kernel(
     int32_t* __restrict__ src_index, const uint8_t* __restrict__ keep_flags,
     const int32_t* __restrict__ cu_q, const int32_t* __restrict__ cu_kept, int budget, int bs,
-    int num_heads) {
+    int num_heads, int tail_blocks) {
   __shared__ int wave_sum_s[4];
   const int r = blockIdx.x, tid = threadIdx.x;
   const int H = num_heads;
-  const SliceGeom g = slice_geom(cu_q, cu_kept, r, budget, bs);
+  const SliceGeom g = slice_geom(cu_q, cu_kept, r, budget, bs, tail_blocks);
   if (g.n_prune == 0) return;  // identity already written by token_select_kernel
   const int n_keep_mid = g.mid - g.n_prune;
   for (int n = tid; n < bs * H; n += SEL_THREADS)
@@ -244,7 +256,7 @@ int64_t pe_prompt_token_select_workspace_bytes(int64_t total_q, int num_kv_heads
 int pe_prompt_token_select(int32_t* src_index, const void* key, const void* value,
                            const int32_t* cu_q, const int32_t* cu_kept, int num_seqs,
                            int64_t total_q, int cache_budget, int block_size, int method,
-                           int compat_q2,
+                           int compat_q2, int tail_blocks,
                            int64_t key_stride, int64_t value_stride, int num_kv_heads,
                            int head_size, int dtype, void* workspace, int64_t workspace_bytes,
                            void* stream) {
@@ -255,8 +267,9 @@ int pe_prompt_token_select(int32_t* src_index, const void* key, const void* valu
              "prompt_token_select: null pointer");
   PE_REQUIRE(method == PE_EVICT_LOCAL || method == PE_EVICT_GLOBAL || method == PE_EVICT_INVERSE_KEY_L2,
              PE_ERR_INVALID_ARG, "token-level prune is defined for local/global/inverse_key_l2");
-  PE_REQUIRE(block_size > 0 && cache_budget >= 3 * block_size, PE_ERR_INVALID_ARG,
-             "cache budget must be at least 3 blocks (kvcache_prunner.py:15)");
+  PE_REQUIRE(block_size > 0 && (cache_budget >= 3 * block_size || (cache_budget == 0 && tail_blocks >= 1)),
+             PE_ERR_INVALID_ARG,
+             "cache budget must be at least 3 blocks (kvcache_prunner.py:15), or 0 with tail_blocks >= 1");
   const int x = 16 / elem_size(dtype);
   PE_REQUIRE(head_size % x == 0 && key_stride % x == 0 && value_stride % x == 0,
              PE_ERR_UNSUPPORTED, "rows must be made of 16-byte chunks");
@@ -276,11 +289,12 @@ int pe_prompt_token_select(int32_t* src_index, const void* key, const void* valu
   if (int rc = check_launch("token_score")) return rc;
   hipLaunchKernelGGL(token_select_kernel, dim3((unsigned)num_kv_heads, (unsigned)num_seqs),
                      dim3(SEL_THREADS), 0, st, src_index, flags, scores, cu_q, cu_kept, cache_budget,
-                     block_size, num_kv_heads, compat_q2);
+                     block_size, num_kv_heads, compat_q2, tail_blocks);
   if (int rc = check_launch("token_select")) return rc;
   if (compat_q2) {
     hipLaunchKernelGGL(token_index_compat_kernel, dim3((unsigned)num_seqs), dim3(SEL_THREADS), 0, st,
-                       src_index, flags, cu_q, cu_kept, cache_budget, block_size, num_kv_heads);
+                       src_index, flags, cu_q, cu_kept, cache_budget, block_size, num_kv_heads,
+                       tail_blocks);
     if (int rc = check_launch("token_index_compat")) return rc;
   }
   return PE_OK;

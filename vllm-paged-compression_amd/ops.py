@@ -335,8 +335,11 @@ def prompt_keep_index_streaming(cu_q: torch.Tensor, cu_kept: torch.Tensor, total
 
 def prompt_token_select(key: torch.Tensor, value: torch.Tensor, cu_q: torch.Tensor,
                         cu_kept: torch.Tensor, total_kept: int, cache_budget: int,
-                        block_size: int, method: str, compat_q2: bool = False) -> torch.Tensor:
-    """Per-(token, head) kept-row index [total_kept, H_kv] int32 of the token-level prompt prune."""
+                        block_size: int, method: str, compat_q2: bool = False,
+                        tail_blocks: int = 1) -> torch.Tensor:
+    """Per-(token, head) kept-row index [total_kept, H_kv] int32 of the token-level prompt prune.
+    cache_budget 0: percentage prune type (the last ``tail_blocks`` blocks stay, the pruned count
+    of a prompt is its length minus its kept length)."""
     dev = _need_gpu(key, value, cu_q, cu_kept)
     T, H, D = key.shape
     idx = torch.empty((total_kept, H), dtype=torch.int32, device=dev)
@@ -345,7 +348,8 @@ def prompt_token_select(key: torch.Tensor, value: torch.Tensor, cu_q: torch.Tens
     ws = _workspace(dev, need, "select")
     _lib.check(lib.pe_prompt_token_select(
         _p(idx), _p(key), _p(value), _p(cu_q), _p(cu_kept), cu_q.numel() - 1, T, cache_budget,
-        block_size, EVICT_METHODS[method], 1 if compat_q2 else 0, key.stride(0), value.stride(0),
+        block_size, EVICT_METHODS[method], 1 if compat_q2 else 0, tail_blocks, key.stride(0),
+        value.stride(0),
         H, D, _dtype_code(key), _p(ws), 0 if ws is None else ws.numel(), _stream(dev)),
         "prompt_token_select")
     return idx

@@ -42,7 +42,7 @@ class KVCachePruner:
         if cache_prune_type == "percentage":
             assert evict_freq is not None and evict_freq >= 1 and num_block_merge >= 2
             assert initial_blocks == 1, "the kept-row index jumps after the first block"
-            if evict_method != "streamingLLM":
+            if evict_method not in ("streamingLLM", "value_l2", "inverse_key_l2"):
                 raise ValueError(f"Unknown prompt eviction method for the percentage type: {evict_method}")
             if self.decode_evict_method not in ("streamingLLM", "value_l2"):
                 raise ValueError("Unknown decode eviction method for the percentage type: "
@@ -105,7 +105,14 @@ class KVCachePruner:
         if cu_kept is None:
             cu_kept = _cumsum(kept, dev)
         total = sum(kept)
-        if self.cache_prune_type == "percentage":
+        if self.cache_prune_type == "percentage" and self.evict_method != "streamingLLM":
+            # token-level scores of that era (kvcache_prunner_old.py:201-262): per head the
+            # lowest-score middle tokens go; "value_l2" is the score the budget type calls "global"
+            method = "global" if self.evict_method == "value_l2" else self.evict_method
+            idx = ops.prompt_token_select(key, value, cu_q, cu_kept, total, 0, self.orig_block_size,
+                                          method, compat_q2=self.cross_head_compat,
+                                          tail_blocks=self.num_block_merge)
+        elif self.cache_prune_type == "percentage":
             # budget 0: the pruned count of each prompt is its length minus its kept length
             idx = ops.prompt_keep_index_streaming(cu_q, cu_kept, total, 0, self.orig_block_size)
         elif self.evict_method in _STREAMING:
