@@ -25,9 +25,12 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for s in syms:
         assert hasattr(lib, s), s
-    assert lib.pe_version() >= 100
+    assert lib.pe_version() >= 101
     # workspace helpers are pure host functions
-    assert lib.pe_paged_decode_workspace_bytes(64, 32, 8, 128, 16, 776) == 0 or True
+    # sized for the largest split count a launch may use: one split per 8 block pairs of 32 tokens
+    assert lib.pe_paged_decode_workspace_bytes(64, 32, 8, 128, 16, 776) == 3 * 64 * 32 * (128 + 2) * 4
+    assert lib.pe_paged_decode_workspace_bytes(64, 32, 8, 128, 16, 300) == 0
+    assert lib.pe_paged_decode_workspace_bytes(0, 32, 8, 128, 16, 776) == 0
     assert lib.pe_prompt_token_select_workspace_bytes(100, 8) == ((100 * 8 * 4 + 255) // 256) * 256 + 800
 
 

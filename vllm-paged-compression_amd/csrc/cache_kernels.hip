@@ -226,7 +226,7 @@ __global__ void copy_blocks_kernel(void* const* __restrict__ key_ptrs,
 extern "C" {
 
 const char* pe_last_error(void) { return pe::g_last_error; }
-int pe_version(void) { return 100; }
+int pe_version(void) { return 101; }  // 101: percentage prune type entry points
 
 int pe_reshape_and_cache(const void* key, const void* value, void* key_cache, void* value_cache,
                          const int64_t* slot_mapping, int64_t num_tokens, int64_t key_stride,
