@@ -31,11 +31,31 @@ def variant(name, text):
             "const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[sub][n][r], scale_log2e, -m_new));",
             "const float p = s[sub][n][r];")
         text = text.replace("if (__builtin_amdgcn_ballot_w64(m_new > m_run[n]) != 0) {", "if (m_new > 1e30f) {")
-    if name in ("nopv", "nopv_novalu"):
+    if name in ("nopv", "nopv_novalu", "qkonly"):
         text = text.replace("for (int n = 0; n < NR; ++n) acc[dt][n] = TR::mfma16(vf, pf[n][k2], acc[dt][n]);",
                             "for (int n = 0; n < NR; ++n) acc[dt][n][0] += (float)vf[n] + (float)pf[n][k2][dt & 7];")
-    if name == "nopv_novalu":
+    if name in ("nopv_novalu", "qkonly"):
         text = variant("novalu", text)
+    if name == "qkonly":     # + no staging, no barrier: QK MFMAs, K and V reads only
+        text = variant("nobar", text)
+    if name == "qk_nov":     # QK MFMAs and K reads only: no V reads, no softmax, no P.V, no staging, no barrier
+        text = variant("qkonly", text)
+        a = text.index("    const int tq = c >> 2, tp = c & 3;")
+        b = text.index("  };\n\n  // ---- main loop")
+        text = text[:a] + ("#pragma unroll\n    for (int sub = 0; sub < 4; ++sub)\n#pragma unroll\n"
+                           "      for (int n = 0; n < NR; ++n) acc[sub][n] += s[sub][n];\n"
+                           "    (void)pf;\n") + text[b:]
+    if name == "qk_noread":  # qk_nov without the K reads: MFMAs on register operands only
+        text = variant("qk_nov", text)
+        text = text.replace("""        dst[ks] = __builtin_bit_cast(
+            vec8, *reinterpret_cast<const u32x4*>(kt + swz_off<D>(sub * 16 + c, 4 * ks + g)));""",
+                            "        dst[ks] = qf[0][(ks + sub) % KS];")
+    if name == "v_noqk":     # V reads + P.V MFMAs only (P = ones), no K reads, no QK, no softmax, no staging, no barrier
+        text = variant("nobar", text)
+        a = text.index("    f32x4 s[4][NR];")
+        b = text.index("    // ---- O^T += V^T.P^T")
+        text = text[:a] + ("    vec8 pf[NR][2];\n#pragma unroll\n    for (int n = 0; n < NR; ++n) { pf[n][0] = ones; pf[n][1] = ones; }\n"
+                           "    (void)n0; (void)kt;\n") + text[b:]
     return text
 
 
