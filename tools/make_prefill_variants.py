@@ -50,6 +50,28 @@ def variant(name, text):
         text = text.replace("""        dst[ks] = __builtin_bit_cast(
             vec8, *reinterpret_cast<const u32x4*>(kt + swz_off<D>(sub * 16 + c, 4 * ks + g)));""",
                             "        dst[ks] = qf[0][(ks + sub) % KS];")
+    if name == "qk_noread32":  # the same flops as qk_noread issued as 16 v_mfma_f32_32x32x16
+        text = variant("qk_nov", text)
+        a = text.index("    f32x4 s[4][NR];")
+        b = text.index("    // ---- mask, online softmax")
+        text = text[:a] + """    f32x4 s[4][NR];
+    f32x16 z[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) z[j][i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        z[j] = TR::mfma32(qf[j % NR][i % KS], qf[(j + 1) % NR][(i + 1) % KS], z[j]);
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+      for (int n = 0; n < NR; ++n)
+        s[sub][n] = f32x4{z[n & 1][4 * sub], z[n & 1][4 * sub + 1], z[n & 1][4 * sub + 2], z[n & 1][4 * sub + 3]};
+    (void)kt;
+""" + text[b:]
     if name == "v_noqk":     # V reads + P.V MFMAs only (P = ones), no K reads, no QK, no softmax, no staging, no barrier
         text = variant("nobar", text)
         a = text.index("    f32x4 s[4][NR];")
