@@ -72,6 +72,10 @@ def variant(name, text):
         s[sub][n] = f32x4{z[n & 1][4 * sub], z[n & 1][4 * sub + 1], z[n & 1][4 * sub + 2], z[n & 1][4 * sub + 3]};
     (void)kt;
 """ + text[b:]
+    if name == "skeleton":   # qk_noread without the MFMAs: what the tile loop itself costs
+        text = variant("qk_noread", text)
+        text = text.replace("s[sub][n] = TR::mfma16(kf[sub & 1][ks], qf[n][ks], s[sub][n]);",
+                            "s[sub][n][ks & 3] += (float)kf[sub & 1][ks][n];")
     if name == "v_noqk":     # V reads + P.V MFMAs only (P = ones), no K reads, no QK, no softmax, no staging, no barrier
         text = variant("nobar", text)
         a = text.index("    f32x4 s[4][NR];")
