@@ -44,11 +44,12 @@ def _decode(ops, q, kc, vc, bt, lens, max_len):
     return out
 
 
-@pytest.mark.parametrize("B,kv_lo,kv_hi,label", [(64, 4096, 4112, "8B 8192->1024 at 50%"),
-                                                 (2, 16384, 16400, "8B 32768->2048 at 50%")])
-def test_decode_full_size_properties(ops, oracle, B, kv_lo, kv_hi, label, monkeypatch):
-    Hq, Hkv, D = 32, 8, 128
-    dt = torch.bfloat16
+@pytest.mark.parametrize("B,kv_lo,kv_hi,Hq,Hkv,D,dt,label", [
+    (64, 4096, 4112, 32, 8, 128, torch.bfloat16, "8B 8192->1024 at 50%"),
+    (2, 16384, 16400, 32, 8, 128, torch.bfloat16, "8B 32768->2048 at 50%"),
+    (64, 3072, 3088, 8, 1, 128, torch.bfloat16, "70B TP=8, one rank's heads, 4096->512 at 25%"),
+    (1, 1024, 1124, 12, 12, 64, torch.float16, "OPT-125m 1024->100, no eviction")])
+def test_decode_full_size_properties(ops, oracle, B, kv_lo, kv_hi, Hq, Hkv, D, dt, label, monkeypatch):
     nblk = kv_hi // BS + 1
     nb = B * nblk + 4
     kc, vc = _cache(nb, Hkv, D, dt, 3)
@@ -60,7 +61,7 @@ def test_decode_full_size_properties(ops, oracle, B, kv_lo, kv_hi, label, monkey
     out = _decode(ops, q, kc, vc, bt, lens, kv_hi)
     assert torch.isfinite(out).all()
     # oracle on a sample of the sequences
-    for s in (0, B - 1):
+    for s in sorted({0, B - 1}):
         ref = oracle.paged_attention(q[s:s + 1].cpu(), kc.cpu(), vc.cpu(), bt[s:s + 1].cpu(),
                                      lens[s:s + 1].cpu(), D ** -0.5)
         torch.testing.assert_close(out[s:s + 1].cpu().float(), ref.float(), atol=1e-3, rtol=1.6e-2)
@@ -68,7 +69,7 @@ def test_decode_full_size_properties(ops, oracle, B, kv_lo, kv_hi, label, monkey
     for splits in ("1", "5"):
         monkeypatch.setenv("PE_DECODE_SPLITS", splits)
         o2 = _decode(ops, q, kc, vc, bt, lens, kv_hi)
-        torch.testing.assert_close(o2.float(), out.float(), atol=1e-3, rtol=1.6e-2)
+        torch.testing.assert_close(o2.float(), out.float(), atol=1e-3, rtol=1.6e-2 if dt == torch.bfloat16 else 1e-3)
     monkeypatch.delenv("PE_DECODE_SPLITS")
     # permutation of the KV blocks (whole blocks only: use the block-aligned length)
     lens_al = torch.full_like(lens, kv_lo)
@@ -77,7 +78,7 @@ def test_decode_full_size_properties(ops, oracle, B, kv_lo, kv_hi, label, monkey
     bt_p = bt.clone()
     bt_p[:, :kv_lo // BS] = bt[:, perm]
     permuted = _decode(ops, q, kc, vc, bt_p, lens_al, kv_lo)
-    torch.testing.assert_close(permuted.float(), base.float(), atol=1e-3, rtol=1.6e-2)
+    torch.testing.assert_close(permuted.float(), base.float(), atol=1e-3, rtol=1.6e-2 if dt == torch.bfloat16 else 1e-3)
     # convexity: constant V -> the constant comes back (softmax weights sum to 1)
     c = torch.empty(Hkv, D, dtype=dt, device="cuda").uniform_(-1, 1, generator=g)
     vc_c = c.view(1, Hkv, D, 1).expand(nb, Hkv, D, BS).contiguous()
