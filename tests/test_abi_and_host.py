@@ -49,6 +49,13 @@ def test_argument_checks_without_gpu():
         _lib.check(rc, "evict_select_compact")
     assert lib.pe_reshape_and_cache(None, None, None, None, None, 0, 0, 0, None, 0, None, 0, 8, 128, 16,
                                     4, 2, None) == 1
+    # a fused decode step the MFMA kernel cannot serve (block size 8) must be refused, not run as
+    # attention-only with the step's token left unwritten; nothing is dereferenced before that
+    p = 1 << 20
+    assert lib.pe_paged_decode_supports_fused_write(32, 8, 128, 8, 2) == 0
+    rc = lib.pe_decode_step(p, p, p, p, p, p, p, p, p, None, 1, 32, 8, 128, 8, 4, 4, 4096, 1024, 1024,
+                            8192, 1024, 0.1, 32, 2, None, 0, None)
+    assert rc == 2 and b"fused KV write" in lib.pe_last_error()
 
 
 def test_ops_reject_cpu_tensors():

@@ -549,7 +549,12 @@ static int decode_impl(void* out, const void* query, const void* key_cache, cons
     return PE_OK;
   }
 
-  // generic path
+  // generic path: attention only - it cannot take the step's token from registers, so a fused
+  // call that lands here must fail instead of silently leaving the cache unwritten
+  PE_REQUIRE(new_key == nullptr, PE_ERR_UNSUPPORTED,
+             "decode_step: fused KV write needs the MFMA path (16-bit dtype, block_size 16, "
+             "head_size 64/128/256, strides multiples of 8); ask "
+             "pe_paged_decode_supports_fused_write first");
   int gen_len = max_seq_len;
   if ((int64_t)max_num_blocks_per_seq * block_size < gen_len) gen_len = max_num_blocks_per_seq * block_size;
   const size_t lds = (size_t)(((head_size + 3) & ~3) + 8 + gen_len) * 4;
