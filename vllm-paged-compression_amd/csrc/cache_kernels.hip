@@ -287,6 +287,9 @@ int pe_prompt_prune_gather(const void* key, const void* value, void* out_key, vo
   if (n_out == 0) return PE_OK;
   PE_REQUIRE(key && value && out_key && out_value && src_index, PE_ERR_INVALID_ARG,
              "prompt_prune_gather: null pointer");
+  PE_REQUIRE(num_kv_heads > 0 && head_size > 0, PE_ERR_INVALID_ARG, "prompt_prune_gather: bad sizes");
+  PE_REQUIRE(((uintptr_t)key | (uintptr_t)value | (uintptr_t)out_key | (uintptr_t)out_value) % 16 == 0,
+             PE_ERR_INVALID_ARG, "prompt_prune_gather: pointers must be 16-byte aligned");
   const int x = 16 / elem_size(dtype);
   PE_REQUIRE(head_size % x == 0 && key_stride % x == 0 && value_stride % x == 0,
              PE_ERR_UNSUPPORTED, "rows must be made of 16-byte chunks");
