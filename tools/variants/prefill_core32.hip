@@ -1,3 +1,11 @@
+// EXPERIMENT, not part of the library (only csrc/*.hip is built): csrc/prefill.hip plus a second
+// MFMA kernel, prefill_mfma32_kernel, built on v_mfma_f32_32x32x16 and selected with
+// PE_PREFILL_CORE=32 (32 query rows per wave, two waves per SIMD) or 64 (64 rows per wave, one
+// wave per SIMD, the vector work of one 32-row group sliced between the MFMAs of the other).
+// Both pass the prefill parity tests.  Measured on MI355X (4 x 8192 causal, 32/8 heads, D 128):
+// 16x16x32 core 2,300 us, core 32 2,360 us, core 64 2,950 us unsliced / 3,105 us sliced.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -I<pkg>/csrc -c this file,
+// link with the other objects of <pkg>/build/ into a library of its own and load that.
 // Varlen causal prefill attention on gfx950 (flash-style, no L_q x L_kv matrix in memory).
 //
 // Mask: query row i of a request attends kv rows 0..min(i, L_kv-1) — the top-left aligned
@@ -19,12 +27,15 @@
 #include <cstdlib>
 #include <type_traits>
 
+#ifndef PF_PIPE_GROUPS
+#define PF_PIPE_GROUPS 1
+#endif
 namespace pe {
 
 constexpr int PF_BN = 64;   // kv rows per tile
 constexpr int PF_DEFAULT_SHAPE = 24;
+constexpr int PF_DEFAULT_CORE = 16;
 constexpr float PF_NEG = -1.0e30f;
-constexpr float PF_LAZY_LOG2 = 6.0f;  // weights may reach 2^6 before the reference point moves
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
@@ -260,20 +271,14 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void prefill_mfma_kernel(
 #pragma unroll
         for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[sub][n][r]);
       mx = max_xor_16_32(mx);
-      // The reference point of the exponentials only has to be NEAR the row's maximum: it moves
-      // (and the accumulators are rescaled) when some row of the wave outgrew it by more than
-      // 2^PF_LAZY_LOG2, so the weights stay below that factor and the rescale, frequent with a
-      // strict running maximum, becomes rare.  The normalised output does not depend on it.
-      const float m_tile = mx * scale_log2e;
-      if (__builtin_amdgcn_ballot_w64(m_tile > m_run[n] + PF_LAZY_LOG2) != 0) {  // wave-uniform
-        const float m_new = fmaxf(m_run[n], m_tile);
+      const float m_new = fmaxf(m_run[n], mx * scale_log2e);
+      if (__builtin_amdgcn_ballot_w64(m_new > m_run[n]) != 0) {  // wave-uniform: some row's max grew
         const float alpha = __builtin_amdgcn_exp2f(m_run[n] - m_new);
         m_run[n] = m_new;
         acc_l[n] *= alpha;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) acc[dt][n] *= alpha;
       }
-      const float m_new = m_run[n];
 #pragma unroll
       for (int sub = 0; sub < 4; ++sub) {
 #pragma unroll
@@ -365,6 +370,441 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void prefill_mfma_kernel(
     const int x = row & 15;
     const u32x2 lo = *reinterpret_cast<const u32x2*>(o_lds + row * (D * 2) + (((2 * ch) ^ x) << 3));
     const u32x2 hi = *reinterpret_cast<const u32x2*>(o_lds + row * (D * 2) + (((2 * ch + 1) ^ x) << 3));
+    if (qrow < lq) {
+      *reinterpret_cast<u32x4*>(out + (int64_t)(q0 + qrow) * out_stride + (int64_t)head * D + ch * 8) =
+          u32x4{lo[0], lo[1], hi[0], hi[1]};
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 32x32 core (head_size 128): the same workgroup shape, tiles and staging as above, with
+// v_mfma_f32_32x32x16.  A 32x32x16 MFMA does twice the work of a 16x16x32 one for the same hold
+// on the SIMD's vector issue port, which leaves the other wave of the SIMD three quarters of the
+// port (instead of half) for its softmax while this one runs its matrix phases.
+//   S^T = K.Q^T    A = 32 K rows x 16 dims (ds_read_b128), B = the wave's 32 query rows.  A lane
+//                  ends up with 32 keys of ONE query row (l % 32): the row max is a register
+//                  reduction + one half swap, the row sum stays per lane until the epilogue.
+//   O^T += V^T.P^T A = V^T (32 dims x 16 keys) by two ds_read_b64_tr_b16, B = P straight from
+//                  the S^T accumulators: k-slot (8h + 4i + r) of step (G, p) stands for key
+//                  32G + 16p + 8i + 4h + r in both operands (h = l / 32).
+template <int D>
+__device__ __forceinline__ int swz_off_v32(int row, int chunk) {
+  // the 32 lanes of a half read 4 consecutive rows x 64 bytes: XOR the 64-byte span index with
+  // the row so that the 4 rows cover the 256-byte bank window once
+  static_assert(D == 128, "32x32 core: head_size 128");
+  return row * (D * 2) + ((chunk ^ ((row & 3) << 2)) << 4);
+}
+
+template <typename T, int D, int WAVES, int QG>
+__global__ __launch_bounds__(WAVES * 64, QG == 1 ? 2 : 1) void prefill_mfma32_kernel(
+    T* __restrict__ out, const T* __restrict__ q, const T* __restrict__ k,
+    const T* __restrict__ v, const int32_t* __restrict__ cu_q, const int32_t* __restrict__ cu_kv,
+    int num_heads, int num_kv_heads, int64_t q_stride, int64_t k_stride, int64_t v_stride,
+    int64_t out_stride, float scale_log2e) {
+  using TR = Traits<T>;
+  using vec8 = typename TR::vec8;
+  constexpr int DS = D / 16;                        // contraction steps of S^T = K.Q^T
+  constexpr int DG = D / 32;                        // 32-dim groups of O^T
+  constexpr int CPR = D / 8;                        // 16-byte chunks per row
+  constexpr int TILE_BYTES = PF_BN * D * 2;         // one K or V tile
+  constexpr int WROWS = 32 * QG;                    // query rows per wave (QG groups of 32)
+  constexpr int BM = WROWS * WAVES;                 // query rows per workgroup
+  static_assert(PF_BN == 64 && BM % PF_BN == 0 && BM * D * 2 <= 4 * TILE_BYTES, "tile shape");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  auto k_tile = [&](int buf) { return smem + buf * 2 * TILE_BYTES; };
+  auto v_tile = [&](int buf) { return smem + buf * 2 * TILE_BYTES + TILE_BYTES; };
+
+  // grid and XCD mapping: as prefill_mfma_kernel
+  const int gqa = num_heads / num_kv_heads;
+  const int lid = (int)blockIdx.x + (int)gridDim.x * (int)blockIdx.y;
+  const int n_groups = num_kv_heads * (int)gridDim.y;
+  int grp, hg;
+  if (n_groups % 8 == 0) {
+    grp = (lid / (8 * gqa)) * 8 + lid % 8;
+    hg = (lid / 8) % gqa;
+  } else {
+    grp = lid / gqa;
+    hg = lid % gqa;
+  }
+  const int seq = grp / num_kv_heads;
+  const int kvh = grp % num_kv_heads;
+  const int head = kvh * gqa + hg;
+  const int q0 = cu_q[seq], lq = cu_q[seq + 1] - q0;
+  const int kv0 = cu_kv[seq], lkv = cu_kv[seq + 1] - kv0;
+  const int qt = (int)gridDim.z - 1 - (int)blockIdx.z;
+  const int m0 = qt * BM;
+  if (m0 >= lq) return;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, c32 = lane & 31;
+  const int wrow0 = m0 + wave * WROWS;
+
+  // ---- Q fragments (B operand): lane holds Q[row l%32][16ds + 8h .. +8) ----
+  vec8 qf[QG][DS];
+#pragma unroll
+  for (int qg = 0; qg < QG; ++qg) {
+    const int row = min(wrow0 + 32 * qg + c32, lq - 1);
+    const T* qp = q + (int64_t)(q0 + row) * q_stride + (int64_t)head * D + 8 * h;
+#pragma unroll
+    for (int ds = 0; ds < DS; ++ds)
+      qf[qg][ds] = __builtin_bit_cast(vec8, *reinterpret_cast<const u32x4*>(qp + 16 * ds));
+  }
+
+  float m_run[QG], l_run[QG];
+  f32x16 acc[QG][DG];
+#pragma unroll
+  for (int qg = 0; qg < QG; ++qg) {
+    m_run[qg] = PF_NEG;
+    l_run[qg] = 0.f;
+#pragma unroll
+    for (int dg = 0; dg < DG; ++dg)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[qg][dg][j] = 0.f;
+  }
+
+  const int kv_end = min(lkv, m0 + BM);
+  const int n_tiles = (kv_end + PF_BN - 1) / PF_BN;
+
+  // ---- staging (LDS-DMA), as prefill_mfma_kernel; the V image uses swz_off_v32 ----
+  constexpr int RPI = 64 / CPR;
+  constexpr int RSTEP = WAVES * RPI;
+  constexpr int NINST = PF_BN / RSTEP;
+  static_assert(RSTEP % 16 == 0 && NINST >= 1 && NINST * RSTEP == PF_BN, "staging shape");
+  const int lrow = wave * RPI + lane / CPR;
+  const int lslot = lane % CPR;
+  const char* k_seq = reinterpret_cast<const char*>(k + (int64_t)kv0 * k_stride + (int64_t)kvh * D);
+  const char* v_seq = reinterpret_cast<const char*>(v + (int64_t)kv0 * v_stride + (int64_t)kvh * D);
+  const uint32_t k_row_bytes = (uint32_t)k_stride * 2u, v_row_bytes = (uint32_t)v_stride * 2u;
+  const uint32_t k_chunk16 = (uint32_t)(swz_off<D>(lrow, lslot) - lrow * (D * 2));
+  const uint32_t v_chunk16 = (uint32_t)(swz_off_v32<D>(lrow, lslot) - lrow * (D * 2));
+  const uint32_t k_lane_off = (uint32_t)lrow * k_row_bytes + k_chunk16;
+  const uint32_t v_lane_off = (uint32_t)lrow * v_row_bytes + v_chunk16;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem +
+                        (uint32_t)wave * 1024u;
+  auto glds16 = [](const char* base, uint32_t lane_off, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_nop 4\n\t"
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(lane_off), "s"(base), "s"(lds_dst)
+        : "memory");
+  };
+  auto stage = [&](int tile, int buf) {
+    const int t0 = tile * PF_BN;
+    const char* kb = k_seq + (int64_t)t0 * k_row_bytes;
+    const char* vb = v_seq + (int64_t)t0 * v_row_bytes;
+    const uint32_t kd = lds0 + (uint32_t)buf * (2u * TILE_BYTES);
+    const uint32_t vd = kd + TILE_BYTES;
+    if (t0 + PF_BN <= lkv) {
+#pragma unroll
+      for (int i = 0; i < NINST; ++i) {
+        glds16(kb + (int64_t)(i * RSTEP) * k_row_bytes, k_lane_off, kd + i * RSTEP * D * 2);
+        glds16(vb + (int64_t)(i * RSTEP) * v_row_bytes, v_lane_off, vd + i * RSTEP * D * 2);
+      }
+    } else {
+      const int last = lkv - 1 - t0;
+#pragma unroll
+      for (int i = 0; i < NINST; ++i) {
+        const uint32_t row = (uint32_t)min(lrow + i * RSTEP, last);
+        glds16(kb, row * k_row_bytes + k_chunk16, kd + i * RSTEP * D * 2);
+        glds16(vb, row * v_row_bytes + v_chunk16, vd + i * RSTEP * D * 2);
+      }
+    }
+  };
+  auto stage_wait = [] { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+
+  auto compute_plain = [&](int tile, int buf, auto masked_tag) {
+    constexpr bool MASKED = decltype(masked_tag)::value;
+    const int n0 = tile * PF_BN;
+    const char* kt = k_tile(buf);
+    const char* vt = v_tile(buf);
+    // ---- S^T = K.Q^T: s[G][j] = key 32G + 8(j/4) + 4h + j%4, query l%32 ----
+    // Fragments are fetched one chunk (2 contraction steps x both key groups) ahead of the MFMAs
+    // that use them; the scheduling fences keep that order.
+    f32x16 s[QG][2];
+    vec8 kf[2][2][2];  // [chunk parity][step in chunk][G]
+    auto load_k = [&](int chunk, vec8 (*dst)[2]) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int G = 0; G < 2; ++G)
+          dst[e][G] = __builtin_bit_cast(
+              vec8, *reinterpret_cast<const u32x4*>(kt + swz_off<D>(32 * G + c32, 2 * (2 * chunk + e) + h)));
+    };
+#pragma unroll
+    for (int qg = 0; qg < QG; ++qg)
+#pragma unroll
+      for (int G = 0; G < 2; ++G)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s[qg][G][j] = 0.f;
+    load_k(0, kf[0]);
+#pragma unroll
+    for (int chunk = 0; chunk < DS / 2; ++chunk) {
+      if (chunk + 1 < DS / 2) load_k(chunk + 1, kf[(chunk + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int G = 0; G < 2; ++G)
+#pragma unroll
+          for (int qg = 0; qg < QG; ++qg)
+            s[qg][G] = TR::mfma32(kf[chunk & 1][e][G], qf[qg][2 * chunk + e], s[qg][G]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- mask, online softmax ----
+    vec8 pf[QG][2][2];  // [qg][G][p]: k-slots 4i + r <- s[qg][G][8p + 4i + r]
+#pragma unroll
+    for (int qg = 0; qg < QG; ++qg) {
+      if constexpr (MASKED) {
+        // last attended 32G + 8(j/4) + j%4
+        const int limit = min(wrow0 + 32 * qg + c32, lkv - 1) - n0 - 4 * h;
+#pragma unroll
+        for (int G = 0; G < 2; ++G)
+#pragma unroll
+          for (int j = 0; j < 16; ++j)
+            s[qg][G][j] = (32 * G + 8 * (j >> 2) + (j & 3) <= limit) ? s[qg][G][j] : PF_NEG;
+      }
+      float mx = PF_NEG;
+#pragma unroll
+      for (int G = 0; G < 2; ++G)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) mx = fmaxf(mx, s[qg][G][j]);
+      {
+        const unsigned u = __float_as_uint(mx);
+        auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+      }
+      const float m_new = fmaxf(m_run[qg], mx * scale_log2e);
+      if (__builtin_amdgcn_ballot_w64(m_new > m_run[qg]) != 0) {  // wave-uniform: some row's max grew
+        const float alpha = __builtin_amdgcn_exp2f(m_run[qg] - m_new);
+        m_run[qg] = m_new;
+        l_run[qg] *= alpha;
+#pragma unroll
+        for (int dg = 0; dg < DG; ++dg) acc[qg][dg] *= alpha;
+      }
+      float psum[2] = {0.f, 0.f};
+#pragma unroll
+      for (int G = 0; G < 2; ++G)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qg][G][j], scale_log2e, -m_new));
+          psum[j & 1] += p;
+          pf[qg][G][j >> 3][j & 7] = (T)p;
+        }
+      l_run[qg] += psum[0] + psum[1];
+    }
+    // ---- O^T += V^T.P^T ----
+    // transposed read: lane i of a 16-lane group addresses row (base + i/4), 4 columns from
+    // 4*(i%4), and receives column i of the group's 4 rows; groups 2h, 2h+1 take the two 16-column
+    // halves of the 32-dim group and the row quad 4h of each 8-key run
+    const int li = lane & 15, tq = li >> 2, tp = li & 3, half = (lane >> 4) & 1;
+#pragma unroll
+    for (int G = 0; G < 2; ++G) {
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+#pragma unroll
+        for (int dg = 0; dg < DG; ++dg) {
+          const int row_lo = 32 * G + 16 * p + 4 * h + tq;
+          const int row_hi = row_lo + 8;
+          const int ch = 4 * dg + 2 * half + (tp >> 1);
+          const int sub8 = (tp & 1) * 8;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4*)(vt + swz_off_v32<D>(row_lo, ch) + sub8));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4*)(vt + swz_off_v32<D>(row_hi, ch) + sub8));
+          typedef __attribute__((ext_vector_type(8))) short s16x8;
+          const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          const vec8 vf = __builtin_bit_cast(vec8, both);
+#pragma unroll
+          for (int qg = 0; qg < QG; ++qg) acc[qg][dg] = TR::mfma32(vf, pf[qg][G][p], acc[qg][dg]);
+        }
+      }
+    }
+  };
+
+
+  // ---- 64 rows per wave, one wave per SIMD: the wave itself runs the vector work of one
+  //      32-row group beside the matrix work of the other ----
+  //   QK(0) | max(0) | QK(1) + exp(0) | max(1) | PV(0) + exp(1) | PV(1)
+  auto compute_pipe = [&](int tile, int buf, auto masked_tag) {
+    constexpr bool MASKED = decltype(masked_tag)::value;
+    const int n0 = tile * PF_BN;
+    const char* kt = k_tile(buf);
+    const char* vt = v_tile(buf);
+    f32x16 s[2][2];
+    u32x4 pfu[2][2][2];  // P fragments, two 16-bit probabilities per dword
+    auto row_max = [&](int qg) -> float {
+      if constexpr (MASKED) {
+        const int limit = min(wrow0 + 32 * qg + c32, lkv - 1) - n0 - 4 * h;
+#pragma unroll
+        for (int G = 0; G < 2; ++G)
+#pragma unroll
+          for (int j = 0; j < 16; ++j)
+            s[qg][G][j] = (32 * G + 8 * (j >> 2) + (j & 3) <= limit) ? s[qg][G][j] : PF_NEG;
+      }
+      float mx = PF_NEG;
+#pragma unroll
+      for (int G = 0; G < 2; ++G)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) mx = fmaxf(mx, s[qg][G][j]);
+      const unsigned u = __float_as_uint(mx);
+      auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+      mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+      const float m_new = fmaxf(m_run[qg], mx * scale_log2e);
+      if (__builtin_amdgcn_ballot_w64(m_new > m_run[qg]) != 0) {
+        const float alpha = __builtin_amdgcn_exp2f(m_run[qg] - m_new);
+        m_run[qg] = m_new;
+        l_run[qg] *= alpha;
+#pragma unroll
+        for (int dg = 0; dg < DG; ++dg) acc[qg][dg] *= alpha;
+      }
+      return m_new;
+    };
+    const int li = lane & 15, tq = li >> 2, tp = li & 3, half = (lane >> 4) & 1;
+    // Explicit slices: each holds one MFMA, the LDS read(s) of the MFMA two slices ahead and
+    // (phases B, C) the exponentials of two scores of the other row group; scheduling fences
+    // between slices keep that order.
+    auto kread = [&](int i) {
+      const int ds = i >> 1, G = i & 1;
+      return __builtin_bit_cast(
+          vec8, *reinterpret_cast<const u32x4*>(kt + swz_off<D>(32 * G + c32, 2 * ds + h)));
+    };
+    auto vread = [&](int i) {
+      const int G = i >> 3, p = (i >> 2) & 1, dg = i & 3;
+      const int row_lo = 32 * G + 16 * p + 4 * h + tq;
+      const int row_hi = row_lo + 8;
+      const int ch = 4 * dg + 2 * half + (tp >> 1);
+      const int sub8 = (tp & 1) * 8;
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) s16x4*)(vt + swz_off_v32<D>(row_lo, ch) + sub8));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) s16x4*)(vt + swz_off_v32<D>(row_hi, ch) + sub8));
+      typedef __attribute__((ext_vector_type(8))) short s16x8;
+      const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      return __builtin_bit_cast(vec8, both);
+    };
+    float psum[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    auto exp_slice = [&](int qg, int i, float m_new) {
+      const int G = i >> 3, j = 2 * (i & 7);
+      const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qg][G][j], scale_log2e, -m_new));
+      const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qg][G][j + 1], scale_log2e, -m_new));
+      psum[qg][0] += p0;
+      psum[qg][1] += p1;
+      typedef T vec2 __attribute__((ext_vector_type(2)));
+      const vec2 c = {(T)p0, (T)p1};
+      uint32_t packed = __builtin_bit_cast(uint32_t, c);
+      // the results are "used" here: without it the pure exp chain is sunk past the next branch
+      // and out of the slice it is meant to fill
+      asm volatile("" : "+v"(packed), "+v"(psum[qg][0]), "+v"(psum[qg][1]));
+      pfu[qg][G][j >> 3][(j & 7) >> 1] = packed;
+    };
+    auto qk_phase = [&](int qg, auto&& side) {
+#pragma unroll
+      for (int G = 0; G < 2; ++G)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s[qg][G][j] = 0.f;
+      vec8 ring[3];
+      ring[0] = kread(0);
+      ring[1] = kread(1);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if (i + 2 < 16) ring[(i + 2) % 3] = kread(i + 2);
+        s[qg][i & 1] = TR::mfma32(ring[i % 3], qf[qg][i >> 1], s[qg][i & 1]);
+        side(i);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    auto pv_phase = [&](int qg, auto&& side) {
+      vec8 ring[3];
+      ring[0] = vread(0);
+      ring[1] = vread(1);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if (i + 2 < 16) ring[(i + 2) % 3] = vread(i + 2);
+        acc[qg][i & 3] = TR::mfma32(ring[i % 3], __builtin_bit_cast(vec8, pfu[qg][i >> 3][(i >> 2) & 1]), acc[qg][i & 3]);
+        side(i);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    auto nothing = [](int) {};
+    qk_phase(0, nothing);
+    const float m0n = row_max(0);
+    __builtin_amdgcn_sched_barrier(0);
+    qk_phase(1, [&](int i) { exp_slice(0, i, m0n); });
+    l_run[0] += psum[0][0] + psum[0][1];
+    const float m1n = row_max(1);
+    __builtin_amdgcn_sched_barrier(0);
+    pv_phase(0, [&](int i) { exp_slice(1, i, m1n); });
+    l_run[1] += psum[1][0] + psum[1][1];
+    pv_phase(1, nothing);
+  };
+  auto compute = [&](int tile, int buf, auto masked_tag) {
+    if constexpr (QG == 2) compute_pipe(tile, buf, masked_tag);
+    else compute_plain(tile, buf, masked_tag);
+  };
+
+  auto run_tiles = [&](int t_begin, int t_end, auto masked_tag) {
+    constexpr bool MASKED = decltype(masked_tag)::value;
+    for (int tile = t_begin; tile < t_end; ++tile) {
+      const int buf = tile & 1;
+      if (tile + 1 < n_tiles) stage(tile + 1, buf ^ 1);
+      if (!MASKED || tile * PF_BN <= wrow0 + WROWS - 1) compute(tile, buf, masked_tag);
+      stage_wait();
+      __syncthreads();
+    }
+  };
+  if (n_tiles > 0) {
+    const int n_full = min(min(m0, lkv) / PF_BN, n_tiles);
+    stage(0, 0);
+#pragma unroll
+    for (int qg = 0; qg < QG; ++qg)
+#pragma unroll
+      for (int ds = 0; ds < DS; ++ds) asm volatile("" : "+v"(qf[qg][ds]));
+    stage_wait();
+    __syncthreads();
+    run_tiles(0, n_full, std::false_type{});
+    run_tiles(n_full, n_tiles, std::true_type{});
+  }
+
+  // ---- epilogue: the two halves of a query row's sum meet, normalise, stage the wave's 32 x D
+  //      tile in LDS (8-byte unit u of row r at unit u ^ r: the 32 lanes of a half cover the
+  //      bank window once), store whole rows ----
+  char* o_lds = smem + wave * (WROWS * D * 2);
+#pragma unroll
+  for (int qg = 0; qg < QG; ++qg) {
+    const unsigned u = __float_as_uint(l_run[qg]);
+    auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const float l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+#pragma unroll
+    for (int dg = 0; dg < DG; ++dg) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        typename TR::vec4 o4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o4[r] = (T)(acc[qg][dg][4 * b + r] * inv);
+        const int unit = 8 * dg + 2 * b + h;  // dims 32dg + 8b + 4h .. +4
+        *reinterpret_cast<typename TR::vec4*>(o_lds + (32 * qg + c32) * (D * 2) + ((unit ^ c32) << 3)) = o4;
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < WROWS * CPR / 64; ++i) {
+    const int idx = lane + i * 64;
+    const int row = idx / CPR, ch = idx % CPR;
+    const int qrow = wrow0 + row;
+    const u32x2 lo = *reinterpret_cast<const u32x2*>(o_lds + row * (D * 2) + (((2 * ch) ^ (row & 31)) << 3));
+    const u32x2 hi = *reinterpret_cast<const u32x2*>(o_lds + row * (D * 2) + (((2 * ch + 1) ^ (row & 31)) << 3));
     if (qrow < lq) {
       *reinterpret_cast<u32x4*>(out + (int64_t)(q0 + qrow) * out_stride + (int64_t)head * D + ch * 8) =
           u32x4{lo[0], lo[1], hi[0], hi[1]};
@@ -467,6 +907,30 @@ extern "C" int pe_prefill_causal(void* out, const void* q, const void* k, const 
       default: PE_LAUNCH_PF(T, HS, 2, 4, 2); break;                                                \
     }                                                                                              \
   } while (0)
+    // PE_PREFILL_CORE=32 selects the 32x32x16 core (head_size 128, default tile shape)
+    static const int core = [] {
+      const char* e = getenv("PE_PREFILL_CORE");
+      return e ? atoi(e) : PF_DEFAULT_CORE;
+    }();
+    if ((core == 32 || core == 64) && head_size == 128 && shape == PF_DEFAULT_SHAPE) {
+      const int bm = core * 4;
+      dim3 grid((unsigned)num_heads, (unsigned)num_seqs, (unsigned)((max_q_len + bm - 1) / bm));
+      const size_t lds = 4 * (size_t)PF_BN * 128 * 2;
+      if (core == 32) {
+        PE_DISPATCH_16(dtype, T,
+                       hipLaunchKernelGGL((prefill_mfma32_kernel<T, 128, 4, 1>), grid, dim3(256), lds,
+                                          st, (T*)out, (const T*)q, (const T*)k, (const T*)v, cu_q,
+                                          cu_kv, num_heads, num_kv_heads, q_stride, k_stride,
+                                          v_stride, out_stride, sl2));
+      } else {
+        PE_DISPATCH_16(dtype, T,
+                       hipLaunchKernelGGL((prefill_mfma32_kernel<T, 128, 4, 2>), grid, dim3(256), lds,
+                                          st, (T*)out, (const T*)q, (const T*)k, (const T*)v, cu_q,
+                                          cu_kv, num_heads, num_kv_heads, q_stride, k_stride,
+                                          v_stride, out_stride, sl2));
+      }
+      return check_launch("prefill_causal");
+    }
     PE_DISPATCH_16(dtype, T, {
       if (head_size == 64) PE_LAUNCH_PF_SHAPE(T, 64);
       else PE_LAUNCH_PF_SHAPE(T, 128);
