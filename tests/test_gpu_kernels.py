@@ -474,6 +474,29 @@ def test_prefill_spike_forces_rescale(ops, oracle):
     torch.testing.assert_close(out.cpu().float(), ref, atol=2e-2, rtol=1.6e-2)
 
 
+@pytest.mark.parametrize("dtype,D,step", [(torch.bfloat16, 128, 0.05), (torch.float16, 128, 0.05),
+                                          (torch.bfloat16, 64, 0.03), (torch.bfloat16, 128, 0.2)])
+def test_prefill_scores_creep_past_reference_point(ops, oracle, dtype, D, step):
+    """Scores that grow by `step` per key: the row maximum drifts a few bits per 64-key tile, so
+    the kernel's reference point for the exponentials lags behind it for a tile or two (weights
+    above 1) before it moves - the normalised output must not notice.  step 0.2 moves it every
+    tile."""
+    g = torch.Generator().manual_seed(21)
+    Hq, Hkv, L = 4, 2, 600
+    u = torch.nn.functional.normalize(torch.randn(D, generator=g), dim=0)
+    sc = D ** -0.5
+    q = (u[None, None, :] * (1.0 / sc) ** 0.5).repeat(L, Hq, 1)
+    q = (q + 0.05 * torch.randn(L, Hq, D, generator=g)).to(dtype)
+    ramp = torch.arange(L, dtype=torch.float32)[:, None, None] * step
+    k = (u[None, None, :] * ramp * (1.0 / sc) ** 0.5).repeat(1, Hkv, 1)
+    k = (k + 0.05 * torch.randn(L, Hkv, D, generator=g)).to(dtype)
+    v = (torch.rand(L, Hkv, D, generator=g) - 0.5).to(dtype)
+    ref = oracle.prefill_attention(q.float(), k.float(), v.float(), [L], [L], sc)
+    out = ops.prefill_causal(q.cuda(), k.cuda(), v.cuda(), _cu([L]).cuda(), _cu([L]).cuda(), L, sc)
+    tol = (2e-2, 1.6e-2) if dtype == torch.bfloat16 else (3e-3, 1e-2)
+    torch.testing.assert_close(out.cpu().float(), ref, atol=tol[0], rtol=tol[1])
+
+
 # ------------------------------------------------------------------ token-level prompt prune
 def test_prompt_token_select_golden(ops, oracle):
     """Against KVCachePruner.prune_prompt outputs (tie-free f32 inputs): the compat layout
