@@ -125,7 +125,8 @@ int pe_paged_decode(void* out, const void* query, const void* key_cache,
  * pe_paged_decode's: the shape must be one pe_paged_decode_supports_fused_write() accepts, and
  * slot_mapping[s] must lie in the last block of sequence s's table (it does for a decode step:
  * slot = table[-1]*block_size + offset), because the write is ordered only against the reads
- * of the workgroup that owns that block.  seq_lens counts the new token. */
+ * of the workgroup that owns that block.  seq_lens counts the new token.  A shape or stride the
+ * fused kernel cannot serve returns PE_ERR_UNSUPPORTED and writes nothing. */
 int pe_paged_decode_supports_fused_write(int num_heads, int num_kv_heads, int head_size,
                                          int block_size, int dtype);
 int pe_decode_step(void* out, const void* query, const void* new_key, const void* new_value,
