@@ -667,38 +667,39 @@ class PagedEvictImpl(_ImplBase):
         bs = self.cache_config.block_size
         table = self._table(values.device)
         keys = self._step_keys(meta)
-        off = 0
-        rows, counts = [], []
-        exact_tp = self._tp_exact_scores()
         H, D = values.shape[1], values.shape[2]
-        if exact_tp:
-            sums = torch.empty(sum(n // bs for n in kept) * bs, dtype=torch.float32,
-                               device=values.device)
-            so = 0
+        if values.stride(2) != 1 or values.stride(1) != D:
+            raise RuntimeError("prompt values must be dense [tokens, heads, head_size] rows")
+        # One launch for the whole batch: block i of the launch starts at token offs[i] of the
+        # dense value tensor (block stride = one token row, block id = token offset) and its
+        # score goes to flat position idx[i] of the score table.
+        width = table.scores.shape[1]
+        offs, idx, rows, counts = [], [], [], []
+        off = 0
         for i, n in enumerate(kept):
             nb = n // bs
             row = table.row_of(keys[i])
             if nb > 0:
-                if exact_tp:
-                    ops.block_token_norm_sums(values[off:off + nb * bs], None, nb,
-                                              ops.SCORE_TOKEN_MAJOR, H, D, bs,
-                                              out=sums[so:so + nb * bs])
-                    so += nb * bs
-                else:
-                    self.kv_cache_pruner.get_block_scores_dense(values[off:off + nb * bs], nb,
-                                                                out=table.scores[row, :nb])
+                offs.extend(range(off, off + nb * bs, bs))
+                idx.extend(range(row * width, row * width + nb))
             rows.append(row)
             counts.append(nb)
             off += n
-        if exact_tp and sums.numel():
-            self._reduce_token_sums(sums)
-            so = 0
-            for row, nb in zip(rows, counts):
-                if nb > 0:
-                    ops.block_score_from_token_sums(sums[so:so + nb * bs], nb, bs,
-                                                    self.total_num_kv_heads, values.dtype,
-                                                    out=table.scores[row, :nb])
-                    so += nb * bs
+        if offs:
+            dev = values.device
+            n_all = len(offs)
+            ids = torch.tensor(offs, dtype=torch.int32, device=dev)
+            dst = torch.tensor(idx, dtype=torch.int64, device=dev)
+            if self._tp_exact_scores():
+                sums = ops.block_token_norm_sums(values, ids, n_all, ops.SCORE_TOKEN_MAJOR, H, D, bs,
+                                                 block_stride=values.stride(0))
+                self._reduce_token_sums(sums)
+                sc = ops.block_score_from_token_sums(sums, n_all, bs, self.total_num_kv_heads,
+                                                     values.dtype)
+            else:
+                sc = ops.block_score_value_l2(values, ids, n_all, ops.SCORE_TOKEN_MAJOR, H, D, bs,
+                                              block_stride=values.stride(0))
+            table.scores.view(-1).index_copy_(0, dst, sc)
         table.set_counts(rows, counts)
 
     # ------------------------------------------------------------------------------- decode
