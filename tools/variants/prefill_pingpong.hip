@@ -1,9 +1,11 @@
 // EXPERIMENT, not part of the library (only csrc/*.hip is built): csrc/prefill.hip plus
-// prefill_pingpong_kernel (PE_PREFILL_CORE=99): 8 waves, the two waves of a SIMD held one slot
-// apart by a workgroup barrier per slot (matrix slot: P.V of tile t-1 + K.Q^T of tile t; vector
-// slot: softmax), group 1 stages the tiles.  Passes the prefill parity tests; as compiled by
-// hipcc it needs 333 VGPRs (77-80 spilled, reloaded inside the slots) and takes 4,800 us at
-// 4 x 8192 against 2,240 us - the schedule itself is untested until the slots fit in registers.
+// prefill_pingpong_kernel (PE_PREFILL_CORE=99): 8 waves, the two waves of a SIMD held one
+// segment apart by a workgroup barrier per segment (matrix segment: P.V of tile t-1 + K.Q^T of
+// tile t; vector segment: softmax); group 1 stages the tiles.  One loop serves both groups:
+// group 0 skips the barrier of the empty first vector segment and so stays one segment ahead.
+// Passes the prefill parity tests.  Measured at 4 x 8192 (plain kernel 2,215 us): two
+// role-specific loops 4,800 us (hipcc: 333 VGPRs, 77 spilled); this single loop (21 spilled,
+// no K look-ahead) 3,350 us.
 // Varlen causal prefill attention on gfx950 (flash-style, no L_q x L_kv matrix in memory).
 //
 // Mask: query row i of a request attends kv rows 0..min(i, L_kv-1) — the top-left aligned
@@ -645,26 +647,22 @@ __global__ __launch_bounds__(512, 2) void prefill_pingpong_kernel(
       }
     };
     // iteration t holds slots 2t and 2t+1; both groups pass two barriers per iteration
-    if (pgrp == 0) {
-      for (int tl = 0; tl <= n_tiles; ++tl) {
-        if (tl >= 1 && active(tl - 1)) pv((tl - 1) & 1);
-        if (tl < n_tiles && active(tl)) qk(tl & 1);
-        __syncthreads();
-        if (tl < n_tiles) do_softmax(tl);
-        __syncthreads();
-      }
-    } else {
-      for (int tl = 0; tl <= n_tiles; ++tl) {
+    // One loop for both groups: segments V_t (softmax of tile t-1) and M_t (P.V of tile t-1,
+    // K.Q^T of tile t), a barrier after each.  Group 0 skips the barrier of the (empty) V_0, which
+    // puts it one segment ahead for the rest of the loop: it runs M_t while group 1 runs V_t.
+    for (int tl = 0; tl <= n_tiles; ++tl) {
+      if (pgrp == 1) {
         if (tl + 1 < n_tiles) stage_k(tl + 1, (tl + 1) & 1);
         if (tl < n_tiles) stage_v(tl, tl & 1);
-        if (tl >= 1) do_softmax(tl - 1);
-        __syncthreads();
-        if (tl >= 1 && active(tl - 1)) pv((tl - 1) & 1);
-        if (tl < n_tiles && active(tl)) qk(tl & 1);
-        stage_wait();
-        __syncthreads();
       }
+      if (tl >= 1) do_softmax(tl - 1);
+      if (pgrp == 1 || tl > 0) __syncthreads();
+      if (tl >= 1 && active(tl - 1)) pv((tl - 1) & 1);
+      if (tl < n_tiles && active(tl)) qk(tl & 1);
+      if (pgrp == 1) stage_wait();
+      __syncthreads();
     }
+    if (pgrp == 0) __syncthreads();
   }
 
   // ---- epilogue: normalise, stage the wave's WROWS x D tile in LDS, store whole rows ---------
