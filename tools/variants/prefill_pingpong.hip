@@ -1,11 +1,14 @@
-// EXPERIMENT, not part of the library (only csrc/*.hip is built): csrc/prefill.hip plus
-// prefill_pingpong_kernel (PE_PREFILL_CORE=99): 8 waves, the two waves of a SIMD held one
-// segment apart by a workgroup barrier per segment (matrix segment: P.V of tile t-1 + K.Q^T of
-// tile t; vector segment: softmax); group 1 stages the tiles.  One loop serves both groups:
-// group 0 skips the barrier of the empty first vector segment and so stays one segment ahead.
-// Passes the prefill parity tests.  Measured at 4 x 8192 (plain kernel 2,215 us): two
-// role-specific loops 4,800 us (hipcc: 333 VGPRs, 77 spilled); this single loop (21 spilled,
-// no K look-ahead) 3,350 us.
+// EXPERIMENT, not part of the library (only csrc/*.hip is built): csrc/prefill.hip plus two
+// barrier-held ping-pong kernels, 8 waves / 256 query rows, the two waves of a SIMD one segment
+// apart (matrix segment: P.V of tile t-1 + K.Q^T of tile t; vector segment: softmax; group 1
+// stages the tiles; one loop serves both groups, group 0 skips the barrier of the empty first
+// vector segment and so stays a segment ahead):
+//   PE_PREFILL_CORE=99  prefill_pingpong_kernel  16x16x32 core, no K look-ahead   3,350 us
+//   PE_PREFILL_CORE=98  prefill_pp32_kernel      32x32x16 core, ring-prefetched    2,460 us
+// (4 x 8192 causal, 32/8 heads, D 128; the library's kernel: 2,215 us; 8 x 1024: 176 / 128 /
+// 100 us).  Both pass the prefill parity tests.  Segment stamps of the second (cycles per tile):
+// group 0: softmax 1,232, wait 920, P.V 864, QK 711, wait 460; group 1: stage issue 652,
+// softmax 1,097, wait 176, P.V 1,402, QK 735, wait 158.
 // Varlen causal prefill attention on gfx950 (flash-style, no L_q x L_kv matrix in memory).
 //
 // Mask: query row i of a request attends kv rows 0..min(i, L_kv-1) — the top-left aligned
@@ -698,6 +701,325 @@ __global__ __launch_bounds__(512, 2) void prefill_pingpong_kernel(
   }
 }
 
+template <int D>
+__device__ __forceinline__ int swz_off_v32(int row, int chunk) {
+  // the 32 lanes of a half read 4 consecutive rows x 64 bytes: XOR the 64-byte span index with
+  // the row so that the 4 rows cover the 256-byte bank window once
+  static_assert(D == 128, "32x32 core: head_size 128");
+  return row * (D * 2) + ((chunk ^ ((row & 3) << 2)) << 4);
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(512, 2) void prefill_pp32_kernel(
+    T* __restrict__ out, const T* __restrict__ q, const T* __restrict__ k,
+    const T* __restrict__ v, const int32_t* __restrict__ cu_q, const int32_t* __restrict__ cu_kv,
+    int num_heads, int num_kv_heads, int64_t q_stride, int64_t k_stride, int64_t v_stride,
+    int64_t out_stride, float scale_log2e) {
+  constexpr int NR = 2, WAVES = 8, SW = 4;  // SW: waves that stage
+  using TR = Traits<T>;
+  using vec8 = typename TR::vec8;
+  constexpr int KS = D / 32;
+  constexpr int DT = D / 16;
+  constexpr int CPR = D / 8;                        // 16-byte chunks per row
+  constexpr int TILE_BYTES = PF_BN * D * 2;         // one K or V tile
+  constexpr int WROWS = 32;                         // query rows per wave
+  constexpr int DS = D / 16, DG = D / 32;
+  constexpr int BM = WROWS * WAVES;                 // query rows per workgroup
+  static_assert(BM % PF_BN == 0 && BM * D * 2 <= 4 * TILE_BYTES, "tile shape");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // [buf][K|V][tile]
+  auto k_tile = [&](int buf) { return smem + buf * 2 * TILE_BYTES; };
+  auto v_tile = [&](int buf) { return smem + buf * 2 * TILE_BYTES + TILE_BYTES; };
+
+  // grid (head, request, query tile): workgroups are dispatched x-fastest, so every request's
+  // heaviest (last) query tiles start first and the short ones fill the tail.  Consecutive
+  // workgroup ids go to consecutive XCDs; the (head, request) plane is re-enumerated so that all
+  // query heads of one (request, KV head) - which read the same K/V - get ids that are equal
+  // modulo 8 and share one XCD's L2 (needs num_kv_heads * num_requests to be a multiple of 8).
+  const int gqa = num_heads / num_kv_heads;
+  const int lid = (int)blockIdx.x + (int)gridDim.x * (int)blockIdx.y;
+  const int n_groups = num_kv_heads * (int)gridDim.y;
+  int grp, hg;
+  if (n_groups % 8 == 0) {
+    grp = (lid / (8 * gqa)) * 8 + lid % 8;
+    hg = (lid / 8) % gqa;
+  } else {
+    grp = lid / gqa;
+    hg = lid % gqa;
+  }
+  const int seq = grp / num_kv_heads;
+  const int kvh = grp % num_kv_heads;
+  const int head = kvh * gqa + hg;
+  const int q0 = cu_q[seq], lq = cu_q[seq + 1] - q0;
+  const int kv0 = cu_kv[seq], lkv = cu_kv[seq + 1] - kv0;
+  const int qt = (int)gridDim.z - 1 - (int)blockIdx.z;
+  const int m0 = qt * BM;
+  if (m0 >= lq) return;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, c32 = lane & 31;
+  const int wrow0 = m0 + wave * WROWS;  // first query row of this wave
+#if PF_PP_GROUP_BY_PARITY
+  const int pgrp = wave & 1, swave = wave >> 1;
+#else
+  const int pgrp = wave >> 2, swave = wave & 3;
+#endif
+
+  // ---- Q fragments (B operand): lane holds Q[row l%32][16ds + 8h .. +8) ----
+  vec8 qf[DS];
+  {
+    const int row = min(wrow0 + c32, lq - 1);
+    const T* qp = q + (int64_t)(q0 + row) * q_stride + (int64_t)head * D + 8 * h;
+#pragma unroll
+    for (int ds = 0; ds < DS; ++ds)
+      qf[ds] = __builtin_bit_cast(vec8, *reinterpret_cast<const u32x4*>(qp + 16 * ds));
+  }
+  float m_run = PF_NEG, l_run = 0.f;
+  f32x16 acc[DG];
+#pragma unroll
+  for (int dg = 0; dg < DG; ++dg)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[dg][j] = 0.f;
+
+  const int kv_end = min(lkv, m0 + BM);  // rows past the last query row are never attended
+  const int n_tiles = (kv_end + PF_BN - 1) / PF_BN;
+
+  // Staging: K/V tiles go global -> LDS directly (global_load_lds_dwordx4, no registers, no
+  // ds_write).  One wave-instruction fills 1 KiB of LDS contiguously in lane order: RPI whole tile
+  // rows, lane l -> row l / CPR, 16-byte slot l % CPR.  The XOR swizzle of the LDS image is applied
+  // to the per-lane SOURCE chunk instead (slot s of a row holds chunk s ^ x(row)).  Wave w issues
+  // instruction i for rows i * RSTEP + w * RPI ..., so x(row) does not depend on i (RSTEP is a
+  // multiple of 16) and the per-lane source offset is one constant; tile and i go into the scalar
+  // base.  Only the ragged last tile of a request clamps its rows per lane.  The loads are asm
+  // statements the compiler does not count: stage_wait() + a barrier must separate them from the
+  // reads of the tile.
+  constexpr int RPI = 64 / CPR;            // tile rows per wave-instruction
+  constexpr int RSTEP = SW * RPI;          // rows between a wave's consecutive instructions
+  constexpr int NINST = PF_BN / RSTEP;     // instructions per wave per operand tile
+  static_assert(RSTEP % 16 == 0 && NINST >= 1 && NINST * RSTEP == PF_BN, "staging shape");
+  const int lrow = swave * RPI + lane / CPR;  // row within a RSTEP group
+  const int lslot = lane % CPR;
+  const char* k_seq = reinterpret_cast<const char*>(k + (int64_t)kv0 * k_stride + (int64_t)kvh * D);
+  const char* v_seq = reinterpret_cast<const char*>(v + (int64_t)kv0 * v_stride + (int64_t)kvh * D);
+  const uint32_t k_row_bytes = (uint32_t)k_stride * 2u, v_row_bytes = (uint32_t)v_stride * 2u;
+  // source chunk for this lane's slot: the inverse of swz_off / swz_off_v (XOR is an involution)
+  const uint32_t k_chunk16 = (uint32_t)(swz_off<D>(lrow, lslot) - lrow * (D * 2));
+  const uint32_t v_chunk16 = (uint32_t)(swz_off_v32<D>(lrow, lslot) - lrow * (D * 2));
+  const uint32_t k_lane_off = (uint32_t)lrow * k_row_bytes + k_chunk16;
+  const uint32_t v_lane_off = (uint32_t)lrow * v_row_bytes + v_chunk16;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem +
+                        (uint32_t)swave * 1024u;
+  auto glds16 = [](const char* base, uint32_t lane_off, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_nop 4\n\t"
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(lane_off), "s"(base), "s"(lds_dst)
+        : "memory");
+  };
+  auto stage_one = [&](const char* seq_base, uint32_t row_bytes, uint32_t lane_off, uint32_t chunk16,
+                       int tile, uint32_t dst) __attribute__((always_inline)) {
+    const int t0 = tile * PF_BN;
+    const char* base = seq_base + (int64_t)t0 * row_bytes;
+    if (t0 + PF_BN <= lkv) {
+#pragma unroll
+      for (int i = 0; i < NINST; ++i)
+        glds16(base + (int64_t)(i * RSTEP) * row_bytes, lane_off, dst + i * RSTEP * D * 2);
+    } else {
+      const int last = lkv - 1 - t0;  // >= 0: a staged tile starts inside the request
+#pragma unroll
+      for (int i = 0; i < NINST; ++i) {
+        const uint32_t row = (uint32_t)min(lrow + i * RSTEP, last);
+        glds16(base, row * row_bytes + chunk16, dst + i * RSTEP * D * 2);
+      }
+    }
+  };
+  auto stage_k = [&](int tile, int buf) __attribute__((always_inline)) {
+    stage_one(k_seq, k_row_bytes, k_lane_off, k_chunk16, tile, lds0 + (uint32_t)buf * (2u * TILE_BYTES));
+  };
+  auto stage_v = [&](int tile, int buf) __attribute__((always_inline)) {
+    stage_one(v_seq, v_row_bytes, v_lane_off, v_chunk16, tile,
+              lds0 + (uint32_t)buf * (2u * TILE_BYTES) + TILE_BYTES);
+  };
+  auto stage_wait = [] { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+
+  f32x16 s[2];      // scores: s[G][j] = key 32G + 8(j/4) + 4h + j%4 for query row l%32
+  u32x4 pfu[2][2];  // probabilities [G][p], two 16-bit values per dword
+  const int li = lane & 15, tq = li >> 2, tp = li & 3, half = (lane >> 4) & 1;
+  // Matrix phases: one MFMA per slice, the LDS read(s) of the MFMA two slices ahead in a ring of
+  // three fragments, a scheduling fence after every slice.
+  auto qk = [&](int buf) __attribute__((always_inline)) {
+    const char* kt = k_tile(buf);
+    auto kread = [&](int i) __attribute__((always_inline)) {
+      const int ds = i >> 1, G = i & 1;
+      return __builtin_bit_cast(
+          vec8, *reinterpret_cast<const u32x4*>(kt + swz_off<D>(32 * G + c32, 2 * ds + h)));
+    };
+#pragma unroll
+    for (int G = 0; G < 2; ++G)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) s[G][j] = 0.f;
+    vec8 ring[3];
+    ring[0] = kread(0);
+    ring[1] = kread(1);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if (i + 2 < 16) ring[(i + 2) % 3] = kread(i + 2);
+      s[i & 1] = TR::mfma32(ring[i % 3], qf[i >> 1], s[i & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  auto softmax = [&](int tile, auto masked_tag) __attribute__((always_inline)) {
+    constexpr bool MASKED = decltype(masked_tag)::value;
+    const int n0 = tile * PF_BN;
+    if constexpr (MASKED) {
+      const int limit = min(wrow0 + c32, lkv - 1) - n0 - 4 * h;  // last attended 32G + 8(j/4) + j%4
+#pragma unroll
+      for (int G = 0; G < 2; ++G)
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+          s[G][j] = (32 * G + 8 * (j >> 2) + (j & 3) <= limit) ? s[G][j] : PF_NEG;
+    }
+    float mx = PF_NEG;
+#pragma unroll
+    for (int G = 0; G < 2; ++G)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) mx = fmaxf(mx, s[G][j]);
+    {
+      const unsigned u = __float_as_uint(mx);
+      auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+      mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
+    const float m_tile = mx * scale_log2e;
+    if (__builtin_amdgcn_ballot_w64(m_tile > m_run + PF_LAZY_LOG2) != 0) {  // wave-uniform
+      const float m_new = fmaxf(m_run, m_tile);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int dg = 0; dg < DG; ++dg) acc[dg] *= alpha;
+    }
+    float psum[2] = {0.f, 0.f};
+    typedef T vec2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int G = 0; G < 2; ++G)
+#pragma unroll
+      for (int j = 0; j < 16; j += 2) {
+        const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[G][j], scale_log2e, -m_run));
+        const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[G][j + 1], scale_log2e, -m_run));
+        psum[0] += p0;
+        psum[1] += p1;
+        const vec2 pr = {(T)p0, (T)p1};
+        pfu[G][j >> 3][(j & 7) >> 1] = __builtin_bit_cast(uint32_t, pr);
+      }
+    l_run += psum[0] + psum[1];
+  };
+  auto pv = [&](int buf) __attribute__((always_inline)) {
+    const char* vt = v_tile(buf);
+    auto vread = [&](int i) __attribute__((always_inline)) {
+      const int G = i >> 3, p = (i >> 2) & 1, dg = i & 3;
+      const int row_lo = 32 * G + 16 * p + 4 * h + tq;
+      const int row_hi = row_lo + 8;
+      const int ch = 4 * dg + 2 * half + (tp >> 1);
+      const int sub8 = (tp & 1) * 8;
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) s16x4*)(vt + swz_off_v32<D>(row_lo, ch) + sub8));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) s16x4*)(vt + swz_off_v32<D>(row_hi, ch) + sub8));
+      typedef __attribute__((ext_vector_type(8))) short s16x8;
+      const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      return __builtin_bit_cast(vec8, both);
+    };
+    vec8 ring[3];
+    ring[0] = vread(0);
+    ring[1] = vread(1);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if (i + 2 < 16) ring[(i + 2) % 3] = vread(i + 2);
+      acc[i & 3] = TR::mfma32(ring[i % 3], __builtin_bit_cast(vec8, pfu[i >> 3][(i >> 2) & 1]), acc[i & 3]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // ---- slots: group 0 has its matrix slot in the even slots, group 1 in the odd ones ----
+  if (n_tiles > 0) {
+    const int n_full = min(min(m0, lkv) / PF_BN, n_tiles);
+    // wave-uniform: a tile that is fully masked for all of this wave's rows is skipped
+    auto active = [&](int t) __attribute__((always_inline)) { return t < n_full || t * PF_BN <= wrow0 + WROWS - 1; };
+    if (pgrp == 1) stage_k(0, 0);
+#pragma unroll
+    for (int ds = 0; ds < DS; ++ds) asm volatile("" : "+v"(qf[ds]));
+    stage_wait();
+    __syncthreads();
+    auto do_softmax = [&](int tl) __attribute__((always_inline)) {
+      if (active(tl)) {
+        if (tl < n_full) softmax(tl, std::false_type{});
+        else softmax(tl, std::true_type{});
+      }
+    };
+    // iteration t holds slots 2t and 2t+1; both groups pass two barriers per iteration
+    // One loop for both groups: segments V_t (softmax of tile t-1) and M_t (P.V of tile t-1,
+    // K.Q^T of tile t), a barrier after each.  Group 0 skips the barrier of the (empty) V_0, which
+    // puts it one segment ahead for the rest of the loop: it runs M_t while group 1 runs V_t.
+    for (int tl = 0; tl <= n_tiles; ++tl) {
+      if (pgrp == 1) {
+        if (tl + 1 < n_tiles) stage_k(tl + 1, (tl + 1) & 1);
+        if (tl < n_tiles) stage_v(tl, tl & 1);
+      }
+      if (tl >= 1) do_softmax(tl - 1);
+      if (pgrp == 1 || tl > 0) __syncthreads();
+      if (tl >= 1 && active(tl - 1)) pv((tl - 1) & 1);
+      if (tl < n_tiles && active(tl)) qk(tl & 1);
+      if (pgrp == 1) stage_wait();
+      __syncthreads();
+    }
+    if (pgrp == 0) __syncthreads();
+  }
+
+  // ---- epilogue: the two halves of a row's sum meet; normalise; stage the wave's 32 x D tile
+  //      in LDS (8-byte unit u of row r at unit u ^ r); store whole rows ----
+  {
+    const unsigned u = __float_as_uint(l_run);
+    auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    l_run = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+  }
+  const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+  char* o_lds = smem + wave * (WROWS * D * 2);
+#pragma unroll
+  for (int dg = 0; dg < DG; ++dg) {
+#pragma unroll
+    for (int bq = 0; bq < 4; ++bq) {
+      typename TR::vec4 o4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o4[r] = (T)(acc[dg][4 * bq + r] * inv);
+      const int unit = 8 * dg + 2 * bq + h;  // dims 32dg + 8bq + 4h .. +4
+      *reinterpret_cast<typename TR::vec4*>(o_lds + c32 * (D * 2) + ((unit ^ c32) << 3)) = o4;
+    }
+  }
+  __syncthreads();
+  typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+#pragma unroll
+  for (int i = 0; i < WROWS * CPR / 64; ++i) {
+    const int idx = lane + i * 64;
+    const int row = idx / CPR, ch = idx % CPR;
+    const int qrow = wrow0 + row;
+    const u32x2 lo = *reinterpret_cast<const u32x2*>(o_lds + row * (D * 2) + (((2 * ch) ^ row) << 3));
+    const u32x2 hi = *reinterpret_cast<const u32x2*>(o_lds + row * (D * 2) + (((2 * ch + 1) ^ row) << 3));
+    if (qrow < lq) {
+      *reinterpret_cast<u32x4*>(out + (int64_t)(q0 + qrow) * out_stride + (int64_t)head * D + ch * 8) =
+          u32x4{lo[0], lo[1], hi[0], hi[1]};
+    }
+  }
+}
+
 // Generic path: one wave per (query row, head); logits of the row in LDS.
 template <typename T>
 __global__ __launch_bounds__(64) void prefill_generic_kernel(
@@ -797,6 +1119,16 @@ extern "C" int pe_prefill_causal(void* out, const void* q, const void* k, const 
       const char* e = getenv("PE_PREFILL_CORE");
       return e ? atoi(e) : 0;
     }();
+    if (core == 98 && head_size == 128) {
+      dim3 grid((unsigned)num_heads, (unsigned)num_seqs, (unsigned)((max_q_len + 255) / 256));
+      const size_t lds = 4 * (size_t)PF_BN * 128 * 2;
+      PE_DISPATCH_16(dtype, T,
+                     hipLaunchKernelGGL((prefill_pp32_kernel<T, 128>), grid, dim3(512), lds, st,
+                                        (T*)out, (const T*)q, (const T*)k, (const T*)v, cu_q, cu_kv,
+                                        num_heads, num_kv_heads, q_stride, k_stride, v_stride,
+                                        out_stride, sl2));
+      return check_launch("prefill_causal");
+    }
     if (core == 99 && head_size == 128) {
       dim3 grid((unsigned)num_heads, (unsigned)num_seqs, (unsigned)((max_q_len + 255) / 256));
       const size_t lds = 4 * (size_t)PF_BN * 128 * 2;
