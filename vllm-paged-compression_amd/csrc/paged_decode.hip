@@ -426,6 +426,17 @@ static int env_int(const char* name, int dflt) {
   return v ? atoi(v) : dflt;
 }
 
+// Upper limit of the split count for a maximum length: every wave of a split must have at least
+// two block pairs.  pe_paged_decode_workspace_bytes sizes the workspace with it and choose_splits
+// never exceeds it, whatever the tunables say.
+static int split_cap(int max_seq_len) {
+  const int n_pairs = (max_seq_len + 31) / 32;
+  int cap = n_pairs / (2 * DEC_WAVES);
+  if (cap < 1) cap = 1;
+  if (cap > 64) cap = 64;
+  return cap;
+}
+
 // Number of KV splits.  A split costs a second (merge) launch and a round trip of the partial
 // results, about 3 us, so it only pays when the workgroups are few AND long.  Measured on MI355X
 // (4 query heads per KV head, head 128): with at most 64 workgroups a split every 12 block pairs
@@ -440,12 +451,8 @@ static int env_int(const char* name, int dflt) {
 static int choose_splits(int num_seqs, int num_kv_heads, int max_seq_len) {
   const int forced = env_int("PE_DECODE_SPLITS", 0);
   const int n_pairs = (max_seq_len + 31) / 32;
-  if (forced > 0) {
-    int max_splits = n_pairs / (2 * DEC_WAVES);
-    if (max_splits < 1) max_splits = 1;
-    if (max_splits > 64) max_splits = 64;
-    return forced < max_splits ? forced : max_splits;
-  }
+  const int cap = split_cap(max_seq_len);
+  if (forced > 0) return forced < cap ? forced : cap;
   static const int min_pairs_env = env_int("PE_DEC_SPLIT_MIN_PAIRS", 0);
   const int64_t wgs = (int64_t)num_seqs * num_kv_heads;
   const int64_t target = 256;  // one workgroup per CU
@@ -453,6 +460,7 @@ static int choose_splits(int num_seqs, int num_kv_heads, int max_seq_len) {
   int max_splits = n_pairs / min_pairs;
   if (max_splits < 1) max_splits = 1;
   if (max_splits > 16) max_splits = 16;
+  if (max_splits > cap) max_splits = cap;
   int splits = (int)(target / wgs);
   if (splits < 1) splits = 1;
   if (splits > max_splits) splits = max_splits;
@@ -479,11 +487,9 @@ int64_t pe_paged_decode_workspace_bytes(int num_seqs, int num_heads, int num_kv_
                                         int head_size, int block_size, int max_seq_len) {
   (void)block_size;
   if (num_seqs <= 0 || num_heads <= 0 || num_kv_heads <= 0) return 0;
-  // sized for the largest split count the heuristic can pick, so a caller may allocate once
-  const int n_pairs = (max_seq_len + 31) / 32;
-  int max_splits = n_pairs / (2 * pe::DEC_WAVES);
+  // sized for the largest split count choose_splits can pick, so a caller may allocate once
+  const int max_splits = pe::split_cap(max_seq_len);
   if (max_splits <= 1) return 0;
-  if (max_splits > 64) max_splits = 64;
   return (int64_t)max_splits * num_seqs * num_heads * pe::ws_stride(head_size) * 4;
 }
 

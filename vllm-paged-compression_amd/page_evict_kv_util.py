@@ -73,3 +73,50 @@ def percentage_decode_trigger(paged_evict_config, seq_len: int, seq_kv_len: int,
     cfg = paged_evict_config
     return (seq_len % (block_size * cfg.evict_freq) == 0
             and seq_kv_len > (cfg.initial_blocks + cfg.num_block_merge) * block_size)
+
+
+def budget_decode_trigger(paged_evict_config, seq_len: int, block_size: int) -> bool:
+    """A decode step of the budget type evicts one block when the logical length (the step's
+    token included) exceeds the budget and sits on a block boundary
+    (vllm/worker/model_runner.py:540-541, torch_cuda_sdpa.py:1390-1403,1491-1498).
+    inverse_key_l2 never removes a block at decode (model_runner.py:545-547)."""
+    cfg = paged_evict_config
+    return (cfg.evict_method in ("streamingLLM", "streamingLLM-1", "global", "local")
+            and seq_len > cfg.cache_budget and seq_len % block_size == 0)
+
+
+def evicted_tokens(paged_evict_config, seq_len: int, seq_kv_len: int, block_size: int) -> int:
+    """Tokens that leave the attention view at the decode step whose logical length is seq_len
+    and whose physical length (before the step's eviction) is seq_kv_len: what the model runner
+    subtracts from seq_kv_lens before attention runs (model_runner.py:538-543).  0 with eviction
+    off (config None)."""
+    cfg = paged_evict_config
+    if cfg is None:
+        return 0
+    if cfg.cache_prune_type == "percentage":
+        return ((cfg.num_block_merge - 1) * block_size
+                if percentage_decode_trigger(cfg, seq_len, seq_kv_len, block_size) else 0)
+    return block_size if budget_decode_trigger(cfg, seq_len, block_size) else 0
+
+
+def adjust_seq_kv_len(paged_evict_config, seq_len: int, seq_kv_len: int, block_size: int) -> int:
+    """seq_kv_len as the attention kernels must see it on this decode step."""
+    return seq_kv_len - evicted_tokens(paged_evict_config, seq_len, seq_kv_len, block_size)
+
+
+def adjust_seq_kv_lens(paged_evict_config, seq_lens, seq_kv_lens, block_size: int):
+    """Array form of adjust_seq_kv_len for a decode batch (numpy int arrays in, int64 array out)."""
+    import numpy as np
+    L = np.asarray(seq_lens, dtype=np.int64)
+    kv = np.asarray(seq_kv_lens, dtype=np.int64)
+    cfg = paged_evict_config
+    if cfg is None:
+        return kv.copy()
+    if cfg.cache_prune_type == "percentage":
+        trig = (L % (block_size * cfg.evict_freq) == 0) & \
+               (kv > (cfg.initial_blocks + cfg.num_block_merge) * block_size)
+        return kv - trig * ((cfg.num_block_merge - 1) * block_size)
+    if cfg.evict_method not in ("streamingLLM", "streamingLLM-1", "global", "local"):
+        return kv.copy()
+    trig = (L > cfg.cache_budget) & (L % block_size == 0)
+    return kv - trig * block_size
