@@ -139,6 +139,26 @@ int pe_decode_step(void* out, const void* query, const void* new_key, const void
                    float scale, int max_seq_len, int dtype, void* workspace,
                    int64_t workspace_bytes, void* stream);
 
+/* pe_paged_decode_noalloc: pe_paged_decode without a caller workspace.  It has no counterpart
+ * in the reference; it exists for callers that cannot allocate device memory around the call
+ * (code under HIP-graph capture, tight serving loops, harnesses that forbid hipMalloc).  The
+ * split-KV partial results go to a scratch array that is part of the library's device image:
+ * pe_paged_decode_noalloc_max_bytes() bytes (8 MiB in the shipped build), held once by every
+ * GPU the library runs on until the process ends.  The call allocates and frees nothing; a call
+ * whose partials would not fit returns PE_ERR_WORKSPACE and launches nothing.  All calls on one
+ * GPU share that GPU's array: calls that overlap on one GPU (different streams or threads) race
+ * on it and must be serialised by the caller.  Every byte of the array that a call reads was
+ * written by the same call, so nothing has to be cleared between calls.  Arguments and results
+ * are those of pe_paged_decode. */
+int64_t pe_paged_decode_noalloc_max_bytes(void);
+int pe_paged_decode_noalloc(void* out, const void* query, const void* key_cache,
+                            const void* value_cache, const int32_t* block_tables,
+                            const int32_t* seq_lens, const float* alibi_slopes, int num_seqs,
+                            int num_heads, int num_kv_heads, int head_size, int block_size,
+                            int max_num_blocks_per_seq, int64_t q_stride, int64_t kv_block_stride,
+                            int64_t kv_head_stride, float scale, int max_seq_len, int dtype,
+                            void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Prefill attention.  Replaces TorchCUDASDPABackendImpl._run_sdpa_forward
  * (vllm/attention/backends/torch_cuda_sdpa.py:1069-1127): per request causal attention

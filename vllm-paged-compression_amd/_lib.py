@@ -24,6 +24,10 @@ SIGNATURES = {
                                 c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int64,
                                 c_int64, c_int64, c_float, c_int, c_int, c_void_p, c_int64,
                                 c_void_p]),
+    "pe_paged_decode_noalloc_max_bytes": (c_int64, []),
+    "pe_paged_decode_noalloc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int64,
+                                        c_int64, c_int64, c_float, c_int, c_int, c_void_p]),
     "pe_paged_decode_supports_fused_write": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "pe_decode_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,

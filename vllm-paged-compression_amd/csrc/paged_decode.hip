@@ -24,6 +24,7 @@
 // f32 too): one workgroup per (head, sequence), logits staged in LDS like the reference.
 #include <cfloat>
 #include <cstdlib>
+#include <mutex>
 
 #include "pe_common.h"
 
@@ -38,6 +39,11 @@ namespace pe {
 #endif
 #ifndef PE_DEC_OCC
 #define PE_DEC_OCC 2  // waves per SIMD the register budget is set for (head sizes up to 128)
+#endif
+// bytes of the file-scope scratch array behind pe_paged_decode_noalloc (held by every GPU the
+// library runs on until the process ends)
+#ifndef PE_NOALLOC_SCRATCH_BYTES
+#define PE_NOALLOC_SCRATCH_BYTES (8 << 20)
 #endif
 constexpr int DEC_WAVES = PE_DEC_WAVES;
 constexpr int DEC_THREADS = DEC_WAVES * 64;
@@ -624,6 +630,67 @@ int pe_decode_step(void* out, const void* query, const void* new_key, const void
                      max_num_blocks_per_seq, q_stride, kv_block_stride, kv_head_stride, scale,
                      max_seq_len, dtype, workspace, workspace_bytes, stream, new_key, new_value,
                      slot_mapping, new_k_stride, new_v_stride, num_blocks * block_size);
+}
+
+
+// ---------------------------------------------------------------------------------------
+// pe_paged_decode_noalloc: the split-KV partials live in a file-scope device array instead of a
+// caller workspace.  Host code never uses the array's name as an address: its device address
+// is looked up once per device with hipGetSymbolAddress and kept in noalloc_scratch_ptr[].
+static __device__ __align__(256) unsigned char scratch[PE_NOALLOC_SCRATCH_BYTES];
+
+namespace pe {
+constexpr int MAX_DEVICES = 64;
+static void* noalloc_scratch_ptr[MAX_DEVICES];
+static std::mutex noalloc_mutex;
+
+// Device address of this GPU's copy of `scratch` (every device holds its own copy at its own
+// address); resolved on the first call made with that device current.
+static int noalloc_scratch(void** ptr_out) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return fail(PE_ERR_LAUNCH, "hipGetDevice: %s", hipGetErrorString(e));
+  PE_REQUIRE(dev >= 0 && dev < MAX_DEVICES, PE_ERR_UNSUPPORTED, "device index %d out of range", dev);
+  std::lock_guard<std::mutex> lock(noalloc_mutex);
+  if (noalloc_scratch_ptr[dev] == nullptr) {
+    void* p = nullptr;
+    e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || p == nullptr)
+      return fail(PE_ERR_LAUNCH, "hipGetSymbolAddress(scratch) on device %d: %s", dev,
+                  hipGetErrorString(e));
+    noalloc_scratch_ptr[dev] = p;
+  }
+  *ptr_out = noalloc_scratch_ptr[dev];
+  return PE_OK;
+}
+}  // namespace pe
+
+int64_t pe_paged_decode_noalloc_max_bytes(void) { return (int64_t)PE_NOALLOC_SCRATCH_BYTES; }
+
+int pe_paged_decode_noalloc(void* out, const void* query, const void* key_cache,
+                            const void* value_cache, const int32_t* block_tables,
+                            const int32_t* seq_lens, const float* alibi_slopes, int num_seqs,
+                            int num_heads, int num_kv_heads, int head_size, int block_size,
+                            int max_num_blocks_per_seq, int64_t q_stride, int64_t kv_block_stride,
+                            int64_t kv_head_stride, float scale, int max_seq_len, int dtype,
+                            void* stream) {
+  using namespace pe;
+  void* ws = nullptr;
+  if (int rc = noalloc_scratch(&ws)) return rc;
+  // decode_impl checks the partials of the split count it picks against the size given here and
+  // reports PE_ERR_WORKSPACE when they do not fit; nothing in it allocates
+  const int rc = decode_impl(out, query, key_cache, value_cache, block_tables, seq_lens,
+                             alibi_slopes, num_seqs, num_heads, num_kv_heads, head_size, block_size,
+                             max_num_blocks_per_seq, q_stride, kv_block_stride, kv_head_stride,
+                             scale, max_seq_len, dtype, ws, (int64_t)PE_NOALLOC_SCRATCH_BYTES,
+                             stream, nullptr, nullptr, nullptr, 0, 0, 0);
+  if (rc == PE_ERR_WORKSPACE)
+    return fail(PE_ERR_WORKSPACE,
+                "pe_paged_decode_noalloc: the split-KV partials of this call (%d sequences, %d "
+                "heads, head size %d, max_seq_len %d) exceed the built-in scratch of %lld bytes; "
+                "use pe_paged_decode with a caller workspace",
+                num_seqs, num_heads, head_size, max_seq_len, (long long)PE_NOALLOC_SCRATCH_BYTES);
+  return rc;
 }
 
 }  // extern "C"
