@@ -15,6 +15,10 @@ prompt prune, value_l2 ("global") block eviction at decode.
   python bench.py --gpus 1 --steps 3 --warmup 1
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N   (tensor parallel:
       heads sharded over the ranks, N x 64 requests - weak scaling)
+  python bench.py --gpus N            (no launcher: starts the N ranks itself, before any GPU call)
+  python bench.py --config c3         (the other BASELINE.json configurations: c1 OPT-125m without
+      eviction, c2 = the default, c3 8192->1024 x 64 at 50 %, c4 70B geometry 4096->512 at 25 %
+      (one rank's heads of TP=8 with --emulate-tp 8), c5 32768->2048 at 50 %)
 
 Prints one JSON line on rank 0.
 """
@@ -31,11 +35,33 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak
+MFMA_PEAK_TFLOPS = 2500.0  # dense bf16/fp16 matrix peak (no sparsity)
+
+# BASELINE.json configurations as flag presets (explicit flags still override them)
+PRESETS = {
+    "c1": dict(num_prompts=1, input_len=1024, output_len=100, evict=0.0, alt_evict=0.0, layers=12,
+               num_heads=12, num_kv_heads=12, head_size=64, dtype="fp16", prefill_batch=1,
+               model="OPT-125m"),
+    "c2": dict(),
+    "c3": dict(num_prompts=64, input_len=8192, output_len=1024, evict=0.5, alt_evict=0.0, steps=1,
+               warmup=1),
+    "c4": dict(num_prompts=64, input_len=4096, output_len=512, evict=0.25, alt_evict=0.0, layers=80,
+               num_heads=64, num_kv_heads=8, steps=1, warmup=1, model="Llama-3-70B"),
+    "c5": dict(num_prompts=64, input_len=32768, output_len=2048, evict=0.5, alt_evict=0.0, steps=1,
+               warmup=0, prefill_batch=1, decode_evict_method="streamingLLM"),
+}
 
 
 def parse():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--config", choices=sorted(PRESETS), default="c2",
+                    help="BASELINE.json configuration (default c2 = the headline: 64 requests "
+                         "1024->100 at 25 %% eviction)")
+    ap.add_argument("--emulate-tp", type=int, default=1,
+                    help="run ONE rank's head shard of a TP=N deployment on this GPU (no collectives)")
+    ap.add_argument("--dtype", choices=["bf16", "fp16"], default="bf16")
+    ap.add_argument("--model", default="Llama-3-8B", help="label only")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
@@ -58,7 +84,7 @@ def parse():
     # commands can be pasted; they select nothing here
     ap.add_argument("--enable-paged-eviction", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--enforce-eager", action="store_true", help=argparse.SUPPRESS)
-    for flag in ("--backend", "--model", "--distributed-executor-backend", "--tensor-parallel-size"):
+    for flag in ("--backend", "--distributed-executor-backend", "--tensor-parallel-size"):
         ap.add_argument(flag, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--evict-prefill", action="store_true",
                     help="prune before prefill attention (default: attend the full prompt, as the "
@@ -84,6 +110,8 @@ def parse():
     ap.add_argument("--alt-evict", type=float, default=0.5,
                     help="second eviction fraction measured after the timed region and reported under "
                          "config.alt (the metric is quoted at 25 %% and 50 %%); 0 = skip")
+    pre, _ = ap.parse_known_args()
+    ap.set_defaults(**PRESETS[pre.config])
     return ap.parse_args()
 
 
@@ -96,7 +124,8 @@ class Workload:
                                                        budget_from_percentage)
         from vllm_paged_compression_amd.parallel import shard_heads
         self.a, self.dev = a, dev
-        self.tp_size, self.tp_group = tp_size, tp_group
+        self.tp_size, self.tp_group, self.tp_rank = tp_size, tp_group, tp_rank
+        self.dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float16
         sh = shard_heads(a.num_heads, a.num_kv_heads, tp_size, tp_rank)
         self.Hq, self.Hkv, self.D, self.bs = sh.num_heads, sh.num_kv_heads, a.head_size, a.block_size
         self.hidden = a.num_heads * a.head_size
@@ -129,7 +158,7 @@ class Workload:
         self.blocks_per_seq_full = -(-(a.input_len + a.output_len) // a.block_size)
         self.num_blocks = B * self.blocks_per_seq + 8
         shape = PagedEvictBackend.get_kv_cache_shape(self.num_blocks, self.bs, self.Hkv, self.D)
-        self.kv = [torch.zeros(shape, dtype=torch.bfloat16, device=dev) for _ in range(a.layers)]
+        self.kv = [torch.zeros(shape, dtype=self.dtype, device=dev) for _ in range(a.layers)]
         self.impls = [PagedEvictBackend.get_impl_cls()(
             self.Hq, self.D, self.D ** -0.5, self.Hkv, None, None, "auto", None, None,
             cache_config=self.ccfg, prefix=f"model.layers.{i}.self_attn.attn",
@@ -143,16 +172,19 @@ class Workload:
         sc = self.D ** -0.5
 
         def rnd(T, H):
-            return torch.empty(T, H * self.D, dtype=torch.bfloat16, device=dev).uniform_(-sc, sc, generator=g)
+            return torch.empty(T, H * self.D, dtype=self.dtype, device=dev).uniform_(-sc, sc, generator=g)
 
         Tp = a.prefill_batch * a.input_len
         self.qp, self.kp, self.vp = rnd(Tp, self.Hq), rnd(Tp, self.Hkv), rnd(Tp, self.Hkv)
         self.qd, self.kd, self.vd = rnd(B, self.Hq), rnd(B, self.Hkv), rnd(B, self.Hkv)
-        self.o_partial_p = torch.zeros(Tp, self.hidden, dtype=torch.bfloat16, device=dev)
-        self.o_partial_d = torch.zeros(B, self.hidden, dtype=torch.bfloat16, device=dev)
-        self.allreduce = tp_size > 1 and a.oproj_allreduce
+        self.allreduce = tp_size > 1 and a.oproj_allreduce and tp_group is not None
+        self.o_partial_p = self.o_partial_d = None
+        if self.allreduce:
+            self.o_partial_p = torch.zeros(Tp, self.hidden, dtype=self.dtype, device=dev)
+            self.o_partial_d = torch.zeros(B, self.hidden, dtype=self.dtype, device=dev)
         # decode-kernel timing (HIP events on the launch stream) of one layer
         self.timed = []          # (start_event, end_event, algorithmic_bytes)
+        self.timed_prefill = []  # (start_event, end_event, flops) per prefill-attention launch
         self.timing_on = False
         self.kv_blocks_peak = 0
 
@@ -166,14 +198,17 @@ class Workload:
     def _build(self, inter, seq_lens, q_lens):
         return self._builder(inter).build(seq_lens, q_lens, -1, len(seq_lens))
 
-    def _layers(self, q, k, v, meta, o_partial, decode_bytes=None):
+    def _layers(self, q, k, v, meta, o_partial, decode_bytes=None, prefill_flops=None):
         """All layers of one step.  For decode steps of the timed region, layers 1..L-1 (layer 0
         also carries the step's eviction launch) are bracketed by one pair of HIP events on the
         launch stream: every launch between them is the decode-attention kernel, so the span
         divided by the launch count is that kernel's average launch duration."""
-        from vllm_paged_compression_amd import parallel
+        from vllm_paged_compression_amd import ops, parallel
         span = (decode_bytes is not None and self.timing_on and not self.allreduce
                 and len(self.impls) > 2)
+        sink = None
+        if prefill_flops is not None and self.timing_on:
+            sink = ops.prefill_event_sink = []
         for li, impl in enumerate(self.impls):
             if span and li == 1:
                 s_ev = torch.cuda.Event(enable_timing=True)
@@ -185,20 +220,29 @@ class Workload:
             e_ev = torch.cuda.Event(enable_timing=True)
             e_ev.record()
             self.timed.append((s_ev, e_ev, decode_bytes, len(self.impls) - 1))
+        if sink is not None:
+            ops.prefill_event_sink = None
+            self.timed_prefill += [(s, e, prefill_flops) for s, e in sink]
 
-    def _evicted_now(self, L, kv_len) -> int:
-        """Tokens that leave the attention view at the decode step whose logical length is L
-        (the kv-length adjustment of model_runner.py:538-543; every request of the batch has the
-        same lengths)."""
-        if self.cfg is None:
-            return 0
-        bs = self.bs
-        if self.percentage:
-            from vllm_paged_compression_amd.page_evict_kv_util import percentage_decode_trigger
-            return ((self.cfg.num_block_merge - 1) * bs
-                    if percentage_decode_trigger(self.cfg, L, int(kv_len), bs) else 0)
-        trig = self.cfg.evict_method != "inverse_key_l2" and L > self.budget and L % bs == 0
-        return bs if trig else 0
+    def _prefill_flops(self, n_req: int) -> float:
+        """4 * Hq * D * sum_i min(i+1, L_kv) per request: both contractions, causal, the kv length
+        being the pruned one when the prompt is pruned before attention."""
+        a = self.a
+        L = a.input_len
+        Lkv = L
+        if self.cfg is not None and not self.cfg.disable_evict_prefill:
+            Lkv = self.impls[0].kv_cache_pruner.get_pruned_length(L)
+        pairs = Lkv * (Lkv + 1) // 2 + (L - Lkv) * Lkv
+        return 4.0 * self.Hq * self.D * pairs * n_req
+
+    @staticmethod
+    def _op(buf, n):
+        return None if buf is None else buf[:n]
+
+    def _progress(self, what: str) -> None:
+        """Long configurations report to stderr so that a watcher sees the run is alive."""
+        if self.a.input_len * self.a.num_prompts >= 1 << 18 and self.tp_rank == 0:
+            print(f"[bench] {what}", file=sys.stderr, flush=True)
 
     # ---- one generation ---------------------------------------------------------------------
     def generate(self):
@@ -223,15 +267,22 @@ class Workload:
                                      query_lens=[L0], context_lens=[0]) for i in grp]
             meta = self._build(inter, [L0] * len(grp), [L0] * len(grp))
             T = len(grp) * L0
-            self._layers(self.qp[:T], self.kp[:T], self.vp[:T], meta, self.o_partial_p[:T])
+            self._layers(self.qp[:T], self.kp[:T], self.vp[:T], meta, self._op(self.o_partial_p, T),
+                         prefill_flops=self._prefill_flops(len(grp)))
+        self._progress("prefill done")
         # decode: one vectorised scheduler step + one metadata build per step
         L = L0
         es = 2
-        for _ in range(a.output_len):
+        for it in range(a.output_len):
             batch = sched.schedule_decode(rids)
             L += 1
-            kv_adj = batch.kv_lens - self._evicted_now(L, batch.kv_lens[0])
-            meta = self._builder([]).build_decode_batch(batch, kv_adj)
+            # kv lengths as attention sees them (the model runner's adjustment on evict steps,
+            # model_runner.py:538-543) come from the package: build_decode_batch applies
+            # page_evict_kv_util.adjust_seq_kv_lens
+            meta = self._builder([]).build_decode_batch(batch)
+            kv_adj = np.asarray(meta.seq_kv_lens, dtype=np.int64)
+            if it % 256 == 255:
+                self._progress(f"decode step {it + 1}/{a.output_len}")
             nbytes = int((2 * kv_adj * self.Hkv * self.D * es + -(-kv_adj // bs) * 4).sum()) \
                 + 2 * B * self.Hq * self.D * es
             self._layers(self.qd, self.kd, self.vd, meta, self.o_partial_d, decode_bytes=nbytes)
@@ -244,6 +295,7 @@ class Workload:
 
     def _generate_per_request(self):
         from vllm_paged_compression_amd.block_table import EvictBlockSpaceManager, EvictionScheduler
+        from vllm_paged_compression_amd.page_evict_kv_util import adjust_seq_kv_len
         a, bs = self.a, self.bs
         B, L0 = a.num_prompts, a.input_len
         sched = EvictionScheduler(EvictBlockSpaceManager(bs, self.num_blocks, self.cfg, watermark=0.0))
@@ -261,16 +313,16 @@ class Workload:
                                      query_lens=[L0], context_lens=[0]) for i in grp]
             meta = self._build(inter, [L0] * len(grp), [L0] * len(grp))
             T = len(grp) * L0
-            self._layers(self.qp[:T], self.kp[:T], self.vp[:T], meta, self.o_partial_p[:T])
+            self._layers(self.qp[:T], self.kp[:T], self.vp[:T], meta, self._op(self.o_partial_p, T),
+                         prefill_flops=self._prefill_flops(len(grp)))
         # decode
         L = L0
         for _ in range(a.output_len):
             tables, kv_lens = sched.schedule_decode(rids)
             L += 1
-            drop = self._evicted_now(L, kv_lens[0])
             inter, kv_adj = [], []
             for i in range(B):
-                kvl = kv_lens[i] - drop
+                kvl = adjust_seq_kv_len(self.cfg, L, kv_lens[i], bs)
                 kv_adj.append(kvl)
                 inter.append(SimpleNamespace(request_id=rids[i], is_prompt=False,
                                              block_tables={i: tables[i]}, seq_kv_lens={i: kvl},
@@ -293,7 +345,9 @@ def cpu_baseline(a, budget):
     """Reference CPU path (csrc/cpu paged_attention_v1 + reshape_and_cache compiled from the
     reference's sources, torch CPU SDPA for prefill, composed like the reference's CPU
     TORCH_SDPA backend) — or the oracle's C port when oracle/_ref is absent — timed on a
-    bounded sample of the same workload and scaled to the whole job."""
+    bounded sample of the same workload and scaled to the whole job.  Every timed piece is run
+    once untimed first; the figure is the median of the repeats."""
+    import statistics
     import torch.nn.functional as F
     from oracle import pe_oracle
     ref_lib = os.path.join(ROOT, "oracle", "_ref", "libpe_ref.so")
@@ -304,23 +358,26 @@ def cpu_baseline(a, budget):
             kind = "reference"
         except Exception:
             kind = "port"
-    cores = torch.get_num_threads() if kind == "reference" else 1
+    threads = torch.get_num_threads()
+    cores = threads if kind == "reference" else 1
     B, Hq, Hkv, D, bs = a.num_prompts, a.num_heads, a.num_kv_heads, a.head_size, a.block_size
     kv_len = (budget + bs // 2) if budget else a.input_len + a.output_len // 2
+    # bounded sample: at most 16 sequences of the batch (decode time scales with the batch)
+    Bs = min(B, 16) if kind == "reference" else min(B, 4)
     nblk = -(-kv_len // bs)
-    dt = torch.bfloat16
+    dt = torch.bfloat16 if a.dtype == "bf16" else torch.float16
+    x = 16 // 2
     sc = D ** -0.5
     g = torch.Generator().manual_seed(0)
-    nb = B * nblk
-    kc = ((torch.rand(nb, Hkv, D // 8, bs, 8, generator=g) * 2 - 1) * sc).to(dt)
+    nb = Bs * nblk
+    kc = ((torch.rand(nb, Hkv, D // x, bs, x, generator=g) * 2 - 1) * sc).to(dt)
     vc = ((torch.rand(nb, Hkv, D, bs, generator=g) * 2 - 1) * sc).to(dt)
-    q = ((torch.rand(B, Hq, D, generator=g) * 2 - 1) * sc).to(dt)
-    k1 = ((torch.rand(B, Hkv, D, generator=g) * 2 - 1) * sc).to(dt)
-    bt = torch.randperm(nb, generator=g).to(torch.int32).reshape(B, nblk)
-    lens = torch.full((B,), kv_len, dtype=torch.int32)
+    q = ((torch.rand(Bs, Hq, D, generator=g) * 2 - 1) * sc).to(dt)
+    k1 = ((torch.rand(Bs, Hkv, D, generator=g) * 2 - 1) * sc).to(dt)
+    bt = torch.randperm(nb, generator=g).to(torch.int32).reshape(Bs, nblk)
+    lens = torch.full((Bs,), kv_len, dtype=torch.int32)
     slots = (bt[:, -1].to(torch.int64) * bs + (kv_len - 1) % bs)
     out = torch.empty_like(q)
-    n_dec = 3 if kind == "reference" else 1
 
     def decode_step():
         if kind == "reference":
@@ -329,35 +386,46 @@ def cpu_baseline(a, budget):
                                                 "auto", 1.0, 1.0, 0, 0, 0, 64, 0)
         else:
             pe_oracle.reshape_and_cache(k1, k1, kc, vc, slots)
-            pe_oracle.paged_attention(q[:4], kc, vc, bt[:4], lens[:4], sc)
+            pe_oracle.paged_attention(q, kc, vc, bt, lens, sc)
 
-    decode_step()
-    t0 = time.perf_counter()
-    for _ in range(n_dec):
-        decode_step()
-    t_dec = (time.perf_counter() - t0) / n_dec
-    if kind == "port":
-        t_dec *= B / 4.0
-    # prefill: one prompt, one layer, torch CPU SDPA with GQA expansion as the CPU backend does
-    Lp = a.input_len
+    def median_time(fn, repeats, budget_s):
+        fn()                                    # warm (page-in, thread pool start)
+        ts = []
+        t_all = time.perf_counter()
+        for _ in range(repeats):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+            if time.perf_counter() - t_all > budget_s and len(ts) >= 3:
+                break
+        return statistics.median(ts), len(ts)
+
+    t_dec, n_dec = median_time(decode_step, 7, 8.0)
+    t_dec *= B / Bs
+    # prefill: one prompt, one layer, torch CPU SDPA with GQA expansion as the CPU backend does;
+    # prompts longer than 4096 are sampled at 4096 and scaled by the causal pair count
+    Lp = min(a.input_len, 4096)
     qp = torch.rand(1, Hq, Lp, D, generator=g).to(dt)
     kp = torch.rand(1, Hkv, Lp, D, generator=g).to(dt).repeat_interleave(Hq // Hkv, dim=1)
-    t0 = time.perf_counter()
-    F.scaled_dot_product_attention(qp, kp, kp, is_causal=True, scale=sc)
-    t_pre = time.perf_counter() - t0
+    t_pre, n_pre = median_time(
+        lambda: F.scaled_dot_product_attention(qp, kp, kp, is_causal=True, scale=sc), 5, 10.0)
+    t_pre *= (a.input_len / Lp) ** 2
     t_job = a.layers * (t_pre * B + t_dec * a.output_len)
     return {
         "value": round(B * a.output_len / t_job, 3), "unit": "output tok/s (attention path only)",
-        "cores": cores, "kind": kind,
-        "sample": f"1 layer: {n_dec} decode steps (KV write + paged_attention_v1, batch "
-                  f"{B if kind == 'reference' else 4}, kv {kv_len}) + SDPA prefill of 1 prompt of {Lp}; "
-                  f"scaled to {a.layers} layers x ({B} prompts + {a.output_len} steps); no eviction logic "
-                  "(the reference's CPU backend has none)"}
+        "cores": cores, "torch_num_threads": threads, "kind": kind,
+        "sample": f"1 layer: median of {n_dec} decode steps (KV write + paged_attention_v1, {Bs} of "
+                  f"the {B} sequences, kv {kv_len}; scaled by {B}/{Bs}) + median of {n_pre} SDPA "
+                  f"prefills of 1 prompt of {Lp}"
+                  + (f" (scaled by ({a.input_len}/{Lp})^2)" if Lp != a.input_len else "")
+                  + f", each after one untimed call; scaled to {a.layers} layers x ({B} prompts + "
+                  f"{a.output_len} steps); no eviction logic (the reference's CPU backend has none)"}
 
 
 def workload_name(a, wl) -> str:
-    return (f"Llama-3-8B attention geometry (Hq {a.num_heads}, Hkv {a.num_kv_heads}, D "
-            f"{a.head_size}, {a.layers} layers), block {a.block_size}, {a.num_prompts} "
+    tp = f", one rank's heads of TP={a.emulate_tp}" if a.emulate_tp > 1 else ""
+    return (f"{a.model} attention geometry (Hq {a.num_heads}, Hkv {a.num_kv_heads}, D "
+            f"{a.head_size}, {a.layers} layers{tp}), block {a.block_size}, {a.num_prompts} "
             f"requests {a.input_len}->{a.output_len}, "
             + ((f"percentage prune type, evict-freq {a.evict_freq}, num-block-merge "
                 f"{a.num_block_merge} ({wl.budget} prompt tokens kept)" if wl.percentage else
@@ -366,38 +434,112 @@ def workload_name(a, wl) -> str:
                if wl.cfg is not None else "no eviction"))
 
 
+def kernel_source_hash() -> str:
+    """SHA-256 over the decode kernel's sources: a stored HBM-traffic ratio is only reused for
+    the code it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("paged_decode.hip", "pe_common.h"):
+        with open(os.path.join(ROOT, "vllm-paged-compression_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def stored_traffic(workload: str, avg_bytes: float):
+    """HBM bytes per decode launch from the PMC passes kept under profiles/ (FETCH_SIZE x2 per
+    the gfx950 correction + WRITE_SIZE, separate runs of this same bench command), as a ratio to
+    the algorithmic bytes.  Used only when workload, byte count and kernel source all match the
+    run the counters were taken on; otherwise traffic is reported as null."""
+    import glob
+    src = kernel_source_hash()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_decode_pmc*.json")), reverse=True):
+        try:
+            pmc = json.load(open(path))
+            if pmc.get("workload") == workload and pmc.get("kernel_source_sha256") == src and \
+                    abs(avg_bytes / pmc["algorithmic_bytes_per_launch"] - 1.0) < 0.05:
+                return int(avg_bytes * pmc["traffic_over_algorithmic"]), os.path.basename(path)
+        except Exception:
+            continue
+    return None, None
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes
+    (torch.distributed.run) before this process has made any GPU call, and pass their exit code
+    on."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__),
+           *sys.argv[1:]]
+    return subprocess.call(cmd)
+
+
+def timed_generations(wl, n, sync, dist, dev, world):
+    t0 = time.perf_counter()
+    for _ in range(n):
+        wl.generate()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
 def main():
     a = parse()
     if os.environ.get("PE_BENCH_HANG_DUMP"):  # stacks of every thread if the run is still going then
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ["PE_BENCH_HANG_DUMP"]), exit=True)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(a.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     # PE_BENCH_DIST_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than
     # ranks (ranks share devices, collectives go through the host); the measured runs use RCCL
     backend = os.environ.get("PE_BENCH_DIST_BACKEND", "nccl")
+    if backend == "nccl" and world > torch.cuda.device_count():
+        raise SystemExit(f"bench.py: {world} ranks need {world} GPUs, {torch.cuda.device_count()} visible "
+                         "(PE_BENCH_DIST_BACKEND=gloo rehearses with shared devices)")
     dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    devices = [dev_index]
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, dev_index)
+        devices = gathered
     n_gpus = world
     tp = a.mode in ("tp", "tp-strong") and world > 1
+    base_prompts, base_prefill = a.num_prompts, a.prefill_batch
     if tp and a.mode == "tp":
         # weak scaling under tensor parallelism: N times the requests over 1/N of the heads
         a.num_prompts *= world
         a.prefill_batch *= world
     import vllm_paged_compression_amd as pkg
     pkg.load_library()
-    wl = Workload(a, dev, world if tp else 1, rank if tp else 0, dist.group.WORLD if tp else None)
+    tp_size, tp_rank, tp_group = (world, rank, dist.group.WORLD) if tp else (1, 0, None)
+    if a.emulate_tp > 1:
+        if world > 1:
+            raise SystemExit("--emulate-tp is a single-GPU view of one rank of a TP deployment")
+        tp_size, tp_rank = a.emulate_tp, 0
+    wl = Workload(a, dev, tp_size, tp_rank, tp_group)
 
     def sync():
         if world > 1:
@@ -413,15 +555,8 @@ def main():
     gc.collect()
     gc.freeze()
     wl.timing_on = True
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        wl.generate()
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = timed_generations(wl, a.steps, sync, dist, dev, world)
+    wl.timing_on = False
     replicas = 1 if (tp or world == 1) else world
     total_tokens = a.num_prompts * a.output_len * a.steps * replicas
     value = total_tokens / dt
@@ -430,30 +565,30 @@ def main():
     durs = [s.elapsed_time(e) * 1e-3 / n for s, e, _, n in wl.timed]   # seconds per launch
     byts = [b for _, _, b, _ in wl.timed]
     roof = None
+    name = workload_name(a, wl)
     if durs:
         avg_t = sum(durs) / len(durs)
         avg_b = sum(byts) / len(byts)
         ach = avg_b / avg_t / 1e9
-        # HBM bytes per launch from the PMC passes kept under profiles/ (FETCH_SIZE x2 per the
-        # gfx950 correction + WRITE_SIZE, averaged over the decode launches of this same bench
-        # command), as a ratio to the algorithmic bytes; applied only to the workload it was
-        # measured on
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_decode_pmc.json")))
-            if pmc["workload"] == workload_name(a, wl) and \
-                    abs(avg_b / pmc["algorithmic_bytes_per_launch"] - 1.0) < 0.05:
-                traffic = int(avg_b * pmc["traffic_over_algorithmic"])
-        except Exception:
-            traffic = None
+        traffic, traffic_src = stored_traffic(name, avg_b) if world == 1 else (None, None)
         roof = {"bound": "hbm", "kernel": "paged_decode_mfma_kernel", "achieved": round(ach, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                "traffic": traffic, "avg_launch_us": round(avg_t * 1e6, 2),
+                "traffic": traffic, "traffic_source": traffic_src,
+                "avg_launch_us": round(avg_t * 1e6, 2),
                 "algorithmic_bytes_per_launch": int(avg_b),
                 "launches_timed": sum(n for _, _, _, n in wl.timed),
                 "includes": "fused KV write of the step's token (pe_decode_step)"}
+    roof_p = None
+    if wl.timed_prefill:
+        pd = [s.elapsed_time(e) * 1e-3 for s, e, _ in wl.timed_prefill]
+        pf = [f for _, _, f in wl.timed_prefill]
+        ach = sum(pf) / sum(pd) / 1e12
+        roof_p = {"bound": "mfma", "kernel": "prefill_mfma_kernel", "achieved": round(ach, 1),
+                  "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
+                  "traffic": None, "avg_launch_us": round(sum(pd) / len(pd) * 1e6, 2),
+                  "flops_per_launch": int(sum(pf) / len(pf)), "launches_timed": len(pd)}
     es = 2
-    blk_bytes = 2 * a.block_size * a.num_kv_heads * a.head_size * es * a.layers
+    blk_bytes = 2 * a.block_size * a.num_kv_heads * a.head_size * es * a.layers // max(a.emulate_tp, 1)
     full_blocks = a.num_prompts * wl.blocks_per_seq_full
     kv = {"kv_gb_held_peak": round(wl.kv_blocks_peak * blk_bytes / 2 ** 30, 3),
           "kv_gb_without_eviction": round(full_blocks * blk_bytes / 2 ** 30, 3)}
@@ -464,45 +599,59 @@ def main():
         "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
         "scaling": "strong" if a.mode == "tp-strong" and world > 1 else "weak", "vs_baseline": None,
-        "dtype": "bf16",
+        "dtype": a.dtype,
         "data": "synthetic",
         "config": {
-            "workload": workload_name(a, wl),
+            "workload": name, "preset": a.config,
             "step": "one full generation of the batch through prefill + decode attention of all layers",
             "parallelism": (f"tp{world}" if tp else f"dp{world}") if world > 1 else "single",
+            "world_size": dist.get_world_size() if world > 1 else 1,
+            "dist_backend": (dist.get_backend() if world > 1 else None),
+            "devices": devices,
             "oproj_allreduce": bool(wl.allreduce), **kv},
     }
     main_budget = wl.budget
+    del wl
+    torch.cuda.empty_cache()
+    if tp and a.mode == "tp":
+        # the same heads-sharded job with the single-GPU request count (what the reference's
+        # --tensor-parallel-size N run of a fixed request set measures): strong scaling
+        import copy
+        a3 = copy.copy(a)
+        a3.num_prompts, a3.prefill_batch = base_prompts, base_prefill
+        wl3 = Workload(a3, dev, world, rank, dist.group.WORLD)
+        wl3.generate()
+        sync()
+        n3 = max(1, min(a.steps, 2))
+        dt3 = timed_generations(wl3, n3, sync, dist, dev, world)
+        out["config"]["tp_strong"] = {
+            "requests": base_prompts, "steps": n3, "scaling": "strong",
+            "value": round(base_prompts * a.output_len * n3 / dt3, 2),
+            "ms_per_step": round(dt3 / n3 * 1e3, 3)}
+        del wl3
+        torch.cuda.empty_cache()
     if a.alt_evict > 0 and a.cache_budget == 0 and a.cache_prune_type == "budget" \
             and abs(a.alt_evict - a.evict) > 1e-9:
         # the same job at the metric's other eviction fraction (outside the timed region above)
         import copy
         a2 = copy.copy(a)
         a2.evict = a.alt_evict
-        main_budget = wl.budget
-        del wl
-        torch.cuda.empty_cache()
-        wl2 = Workload(a2, dev, world if tp else 1, rank if tp else 0, dist.group.WORLD if tp else None)
+        wl2 = Workload(a2, dev, tp_size, tp_rank, tp_group)
         wl2.generate()
         sync()
-        t0 = time.perf_counter()
         n2 = max(1, min(a.steps, 2))
-        for _ in range(n2):
-            wl2.generate()
-        sync()
-        dt2 = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt2], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt2 = float(t.item())
+        dt2 = timed_generations(wl2, n2, sync, dist, dev, world)
         held2 = wl2.kv_blocks_peak * blk_bytes / 2 ** 30
         out["config"]["alt"] = {
             "evict": a.alt_evict, "budget": wl2.budget, "steps": n2,
             "value": round(a.num_prompts * a.output_len * n2 * replicas / dt2, 2),
             "ms_per_step": round(dt2 / n2 * 1e3, 3), "kv_gb_held_peak": round(held2, 3),
             "kv_gb_saved": round(kv["kv_gb_without_eviction"] - held2, 3)}
+        del wl2
     if roof is not None:
         out["roofline"] = roof
+    if roof_p is not None:
+        out["roofline_prefill"] = roof_p
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(a, main_budget)

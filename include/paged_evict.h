@@ -60,6 +60,21 @@ typedef enum {
 const char* pe_last_error(void);
 int pe_version(void);
 
+/* Conditions a kernel survives by clamping but that mean the caller passed inconsistent
+ * arguments (the reference's kernels would read out of bounds instead).  The kernels record
+ * them in device memory; pe_device_diagnostics copies the flags of the current device to the
+ * host (it synchronises the device: a debugging / test call, not for the serving loop) and
+ * clears them when reset != 0. */
+enum {
+  PE_DIAG_DECODE_LEN_CLAMPED = 1, /* pe_paged_decode / pe_decode_step: a seq_lens entry exceeded
+                                     max_num_blocks_per_seq * block_size (or, on the generic
+                                     path, max_seq_len) and was clamped                        */
+  PE_DIAG_SCORE_ROW_FULL = 2      /* pe_evict_select_compact: a sequence's score row already
+                                     held score_table_width entries; the new block's score was
+                                     not appended                                              */
+};
+int pe_device_diagnostics(unsigned int* flags_out, int reset);
+
 /* ------------------------------------------------------------------------------------
  * KV write.  Replaces torch.ops._C_cache_ops.reshape_and_cache
  * (csrc/torch_bindings.cpp:444-450, kernel csrc/cache_kernels.cu:152-204,263-289;
@@ -121,12 +136,23 @@ int pe_paged_decode(void* out, const void* query, const void* key_cache,
  * slot_mapping int64[num_seqs], negative = skip) fused in front of the attention of
  * pe_paged_decode.  Replaces the reshape_and_cache + paged_attention_v1/v2 pair that the
  * reference issues per layer in its decode branch
- * (vllm/attention/backends/torch_cuda_sdpa.py:936,947,1049-1062).  Requirements beyond
- * pe_paged_decode's: the shape must be one pe_paged_decode_supports_fused_write() accepts, and
- * slot_mapping[s] must lie in the last block of sequence s's table (it does for a decode step:
- * slot = table[-1]*block_size + offset), because the write is ordered only against the reads
- * of the workgroup that owns that block.  seq_lens counts the new token.  A shape or stride the
- * fused kernel cannot serve returns PE_ERR_UNSUPPORTED and writes nothing. */
+ * (vllm/attention/backends/torch_cuda_sdpa.py:936,947,1049-1062).  The kernel takes the step's
+ * token from new_key/new_value in registers as logical position seq_lens[s]-1, reads only the
+ * seq_lens[s]-1 older tokens from the cache, and stores the new row to slot_mapping[s] without
+ * reading it back.  Requirements beyond pe_paged_decode's:
+ *   - the shape must be one pe_paged_decode_supports_fused_write() accepts;
+ *   - seq_lens[s] counts the new token;
+ *   - slot_mapping[s] must be the slot of that position in the table the call is given:
+ *       block_tables[s][(seq_lens[s]-1) / block_size] * block_size + (seq_lens[s]-1) % block_size
+ *     (a decode step's slot mapping satisfies this, also on an eviction step, where the call
+ *     gets the compacted table and the length shortened by one block: the step's token is the
+ *     last token of the sequence's last block in both views).  The kernel does not check it: a
+ *     slot that is inconsistent with the table leaves this step's output correct and the cache
+ *     wrong for later steps.
+ * A negative slot (padding) or one beyond num_blocks*block_size skips the fusion for that
+ * sequence: nothing is stored and all seq_lens[s] positions are read from the cache, as
+ * pe_paged_decode does.  A shape or stride the fused kernel cannot serve returns
+ * PE_ERR_UNSUPPORTED and writes nothing. */
 int pe_paged_decode_supports_fused_write(int num_heads, int num_kv_heads, int head_size,
                                          int block_size, int dtype);
 int pe_decode_step(void* out, const void* query, const void* new_key, const void* new_value,

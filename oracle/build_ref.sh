@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # TEST INFRASTRUCTURE ONLY.
 # Compiles the reference's CPU kernels for this path *in place* from
-# /root/reference/csrc/cpu/{cache,attention}.cpp (no sources are copied) together
+# /root/reference/csrc/cpu/{cache,attention,pos_encoding}.cpp (no sources are copied) together
 # with oracle/ref_binding.cpp into oracle/_ref/libpe_ref.so.  The reference's own
 # build system (cmake + generated registration) is not used.  -mavx512bf16 is left
 # out on purpose: gcc 11 lacks the intrinsic cpu_types_x86.hpp:579 needs, so the
@@ -26,7 +26,7 @@ TORCH_LIB=$(python3 -c "import torch.utils.cpp_extension as e; print(e.library_p
 PY_INC=$(python3 -c "import sysconfig; print(sysconfig.get_paths()['include'])")
 CXXFLAGS="-std=c++17 -O2 -fPIC -fopenmp -mavx512f -mavx512vl -mavx512bw -mavx512dq -mf16c -DVLLM_CPU_EXTENSION -D_GLIBCXX_USE_CXX11_ABI=1 -w"
 newer() { [ ! -f "$2" ] || [ "$1" -nt "$2" ]; }
-for f in cache attention; do
+for f in cache attention pos_encoding; do
   if newer "$REF/csrc/cpu/$f.cpp" "$OUT/$f.o"; then
     g++ $CXXFLAGS $TORCH_INC -I"$PY_INC" -I"$REF/csrc/cpu" -I"$REF/csrc" -c "$REF/csrc/cpu/$f.cpp" -o "$OUT/$f.o" &
   fi
@@ -35,6 +35,6 @@ if newer "$HERE/ref_binding.cpp" "$OUT/ref_binding.o"; then
   g++ $CXXFLAGS $TORCH_INC -I"$PY_INC" -c "$HERE/ref_binding.cpp" -o "$OUT/ref_binding.o" &
 fi
 wait
-g++ -shared -fopenmp -o "$OUT/libpe_ref.so" "$OUT/cache.o" "$OUT/attention.o" "$OUT/ref_binding.o" \
+g++ -shared -fopenmp -o "$OUT/libpe_ref.so" "$OUT/cache.o" "$OUT/attention.o" "$OUT/pos_encoding.o" "$OUT/ref_binding.o" \
   -L"$TORCH_LIB" -Wl,-rpath,"$TORCH_LIB" -ltorch -ltorch_cpu -lc10
 echo "build_ref: built $OUT/libpe_ref.so"

@@ -343,6 +343,24 @@ def decode_streaming(seq_lens: Sequence[int], block_tables: Sequence[Sequence[in
     return rmv, zero_slots
 
 
+def decode_inverse_key_l2(seq_lens: Sequence[int], block_tables: Sequence[Sequence[int]],
+                          budget: int, block_size: int, rng) -> List[int]:
+    """_prune_decode_reqs_inverseKeyL2, torch_cuda_sdpa.py:1435-1475: every sequence whose
+    logical length exceeds the budget gets one slot zeroed per step - a random block of the
+    middle of its table (first and last excluded, :1451), then a random slot of it (:1452); no
+    block is removed and kv lengths are not adjusted (vllm/worker/model_runner.py:545-547).
+    ``rng`` supplies ``randint`` (the reference draws from the global ``random`` module, seeded
+    1234 by the impl constructor, :796).  Returns the slot ids in batch order."""
+    slots: List[int] = []
+    for L, ids in zip(seq_lens, block_tables):
+        if L <= budget:
+            continue
+        b = rng.randint(1, len(ids) - 2)
+        s = rng.randint(0, block_size - 1)
+        slots.append(ids[b] * block_size + s)
+    return slots
+
+
 def argmin_first(scores: Sequence[float], start: int, end: int) -> int:
     """Arg-min with first-min-wins (strict <), torch_cuda_sdpa.py:1536-1541."""
     r = start

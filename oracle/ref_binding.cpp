@@ -2,11 +2,11 @@
 // product path.
 //
 // Registers the reference's own CPU kernels (compiled in place from
-// /root/reference/csrc/cpu/{cache,attention}.cpp by oracle/build_ref.sh) as
+// /root/reference/csrc/cpu/{cache,attention,pos_encoding}.cpp by oracle/build_ref.sh) as
 // torch ops in the namespace `pe_ref`, so that tests and the CPU-baseline leg of
 // bench.py can run the reference's reshape_and_cache / paged_attention_v1/v2 /
-// copy_blocks on host tensors.  The schemas follow
-// csrc/cpu/torch_bindings.cpp:28-51,132-152 of the reference; nothing here is a
+// copy_blocks / rotary_embedding on host tensors.  The schemas follow
+// csrc/cpu/torch_bindings.cpp:28-51,92-98,132-152 of the reference; nothing here is a
 // stand-in for reference code — the function bodies live in the reference's files.
 #include <torch/all.h>
 #include <torch/library.h>
@@ -45,7 +45,16 @@ void reshape_and_cache(torch::Tensor& key, torch::Tensor& value,
                        const std::string& kv_cache_dtype, const double k_scale,
                        const double v_scale);
 
+void rotary_embedding(torch::Tensor& positions, torch::Tensor& query,
+                      torch::Tensor& key, int64_t head_size,
+                      torch::Tensor& cos_sin_cache, bool is_neox);
+
 TORCH_LIBRARY(pe_ref, ops) {
+  ops.def(
+      "rotary_embedding(Tensor positions, Tensor! query,"
+      "                 Tensor! key, int head_size,"
+      "                 Tensor cos_sin_cache, bool is_neox) -> ()");
+  ops.impl("rotary_embedding", torch::kCPU, &rotary_embedding);
   ops.def(
       "paged_attention_v1("
       "    Tensor! out, Tensor query, Tensor key_cache,"

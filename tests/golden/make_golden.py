@@ -3,8 +3,8 @@ code* in the build container:
 
 * ``vllm/attention/kvcache_prunner.py`` and ``vllm/attention/block_l2norm_manager.py``
   are loaded straight from the reference checkout (they import only torch/stdlib);
-* the reference's CPU kernels (``csrc/cpu/cache.cpp``, ``csrc/cpu/attention.cpp``)
-  are used through ``oracle/_ref/libpe_ref.so`` (built by ``oracle/build_ref.sh``).
+* the reference's CPU kernels (``csrc/cpu/cache.cpp``, ``csrc/cpu/attention.cpp``,
+  ``csrc/cpu/pos_encoding.cpp``) are used through ``oracle/_ref/libpe_ref.so`` (built by ``oracle/build_ref.sh``).
 
 Only data (inputs and expected outputs) is written; no reference source travels.
 Run:  python tests/golden/make_golden.py  [--reference /root/reference]
@@ -309,6 +309,35 @@ def main():
             out[f"c{case}_{n}"] = bits(t)
         case += 1
     np.savez_compressed(os.path.join(HERE, "ref_cpu_kernels.npz"), **out)
+
+    # ---- (vii) reference CPU rotary embedding (csrc/cpu/pos_encoding.cpp) -------------
+    # cos/sin table as vllm/model_executor/layers/rotary_embedding.py:_compute_cos_sin_cache
+    # builds it (base 10000); query and key are column slices of one fused qkv buffer, as in
+    # models/llama.py:202-205
+    out = {}
+    case = 0
+    DT = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+    for dtype, Hq, Hkv, D, rot, neox in [(torch.bfloat16, 4, 2, 128, 128, True),
+                                         (torch.bfloat16, 4, 2, 128, 128, False),
+                                         (torch.float16, 6, 6, 64, 64, True),
+                                         (torch.bfloat16, 4, 1, 128, 64, True),
+                                         (torch.float32, 2, 2, 64, 32, False)]:
+        g = torch.Generator().manual_seed(300 + case)
+        T, max_pos = 11, 64
+        inv_freq = 1.0 / (10000.0 ** (torch.arange(0, rot, 2, dtype=torch.float) / rot))
+        freqs = torch.einsum("i,j -> ij", torch.arange(max_pos, dtype=torch.float), inv_freq)
+        cache = torch.cat((freqs.cos(), freqs.sin()), dim=-1).to(dtype)
+        qkv = ((torch.rand(T, (Hq + 2 * Hkv) * D, generator=g) * 2 - 1) * 2).to(dtype)
+        pos = torch.randint(0, max_pos, (T,), generator=g, dtype=torch.int64)
+        q, k = qkv[:, :Hq * D], qkv[:, Hq * D:(Hq + Hkv) * D]
+        q_in, k_in = q.clone(), k.clone()
+        torch.ops.pe_ref.rotary_embedding(pos, q, k, D, cache, neox)
+        out[f"c{case}_meta"] = np.array([Hq, Hkv, D, rot, int(neox), DT[dtype]])
+        for n, t in [("pos", pos), ("cache", cache), ("q_in", q_in), ("k_in", k_in),
+                     ("q_out", q.contiguous()), ("k_out", k.contiguous())]:
+            out[f"c{case}_{n}"] = bits(t)
+        case += 1
+    np.savez_compressed(os.path.join(HERE, "ref_cpu_rope.npz"), **out)
     print("golden vectors written to", HERE)
 
 

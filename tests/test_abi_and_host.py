@@ -299,3 +299,62 @@ def test_launcher_signature_is_view_invariant():
     b = DecodeLayerLauncher.signature(q.view(5, 4, 16), k.view(5, 2, 16), k.view(5, 2, 16), kv)
     assert a == b
     assert a != DecodeLayerLauncher.signature(q[:4], k[:4], k[:4], kv)
+
+
+def test_budget_not_a_multiple_of_the_block_size():
+    """A budget that is not a whole number of blocks must not reach the kernels: with block 16,
+    budget 200 and a 201-token prompt the pruned-length formula gives 209 > 201 kept tokens
+    (vllm/attention/kvcache_prunner.py:284-326; the reference then fails in a copy_)."""
+    from vllm_paged_compression_amd.config import PagedEvictConfig
+    from vllm_paged_compression_amd.page_evict_kv_util import get_num_required_blocks_after_prune_promt
+    from vllm_paged_compression_amd.pruner import KVCachePruner
+    cfg = PagedEvictConfig(True, "budget", "streamingLLM", 1000, -1)
+    assert cfg.cache_budget == 992                      # rounded down, like the < 128 clamp
+    assert PagedEvictConfig(True, "budget", "global", 200, -1).cache_budget == 192
+    with pytest.raises(ValueError, match="multiple of the block size"):
+        KVCachePruner("budget", "streamingLLM", 16, 200, 1)
+    with pytest.raises(ValueError, match="multiple of the block size"):
+        KVCachePruner("budget", "global", 32, 784, 1)    # a multiple of 16 but not of 32
+    # kept never exceeds the prompt, whatever the budget object says
+    raw = PagedEvictConfig(True, "budget", "streamingLLM", 192, -1)
+    raw.cache_budget = 200                              # as a foreign config object could carry it
+    for L in range(180, 260):
+        nblk, kept = get_num_required_blocks_after_prune_promt(L, raw, 16)
+        assert kept <= L and nblk == -(-kept // 16)
+    pr = KVCachePruner("budget", "streamingLLM", 16, 192, 1)
+    for L in range(1, 400):
+        assert pr.get_pruned_length(L) <= L
+
+
+def test_kv_len_adjustment_helpers(oracle):
+    """page_evict_kv_util.adjust_seq_kv_len(s) = the model runner's pre-attention adjustment
+    (vllm/worker/model_runner.py:538-547): one block less on the steps that evict, nothing for
+    inverse_key_l2 or with eviction off."""
+    import numpy as np
+    from vllm_paged_compression_amd.config import PagedEvictConfig
+    from vllm_paged_compression_amd.page_evict_kv_util import (
+        adjust_seq_kv_len, adjust_seq_kv_lens, budget_decode_trigger, evicted_tokens,
+        percentage_decode_trigger)
+    bs = 16
+    Ls = np.arange(100, 400)
+    kv = np.minimum(Ls, 150)
+    for method in ("streamingLLM", "streamingLLM-1", "global", "local"):
+        cfg = PagedEvictConfig(True, "budget", method, 128, 3)
+        for L, k in zip(Ls.tolist(), kv.tolist()):
+            trig = oracle.decode_trigger(L, 128, bs)
+            assert budget_decode_trigger(cfg, L, bs) == trig
+            assert evicted_tokens(cfg, L, k, bs) == (bs if trig else 0)
+            assert adjust_seq_kv_len(cfg, L, k, bs) == k - (bs if trig else 0)
+        want = [adjust_seq_kv_len(cfg, L, k, bs) for L, k in zip(Ls.tolist(), kv.tolist())]
+        assert adjust_seq_kv_lens(cfg, Ls, kv, bs).tolist() == want
+    cfg = PagedEvictConfig(True, "budget", "inverse_key_l2", 128, -1)
+    assert not any(budget_decode_trigger(cfg, int(L), bs) for L in Ls)
+    assert adjust_seq_kv_lens(cfg, Ls, kv, bs).tolist() == kv.tolist()
+    assert adjust_seq_kv_lens(None, Ls, kv, bs).tolist() == kv.tolist()
+    assert adjust_seq_kv_len(None, 160, 150, bs) == 150
+    pct = PagedEvictConfig(True, "percentage", "streamingLLM", 0, -1, evict_freq=2, num_block_merge=3)
+    want = [k - (2 * bs if percentage_decode_trigger(pct, L, k, bs) else 0)
+            for L, k in zip(Ls.tolist(), kv.tolist())]
+    assert adjust_seq_kv_lens(pct, Ls, kv, bs).tolist() == want
+    assert [adjust_seq_kv_len(pct, L, k, bs) for L, k in zip(Ls.tolist(), kv.tolist())] == want
+    assert any(w != k for w, k in zip(want, kv.tolist()))

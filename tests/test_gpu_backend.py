@@ -36,6 +36,7 @@ def test_backend_generation_trace(oracle, method, disable_evict_prefill):
     from vllm_paged_compression_amd.backend import PagedEvictBackend
     from vllm_paged_compression_amd.block_table import EvictBlockSpaceManager, EvictionScheduler
     from vllm_paged_compression_amd.config import CacheConfigView, PagedEvictConfig
+    from vllm_paged_compression_amd.page_evict_kv_util import adjust_seq_kv_len
 
     g = torch.Generator().manual_seed(31)
     Hq, Hkv, D, L_layers, nb = 8, 2, 128, 2, 96
@@ -118,9 +119,9 @@ def test_backend_generation_trace(oracle, method, disable_evict_prefill):
             sid = seq_of[rid]
             seq_len[rid] += 1
             L = seq_len[rid]
-            kvl = kv_lens[sid]
-            if oracle.decode_trigger(L, budget, BS):   # model_runner.py:538-543
-                kvl -= BS
+            # the model runner's adjustment (model_runner.py:538-543), from the package helper
+            kvl = adjust_seq_kv_len(cfg, L, kv_lens[sid], BS)
+            assert kvl == kv_lens[sid] - (BS if oracle.decode_trigger(L, budget, BS) else 0)
             logical.append(L)
             kv_adj.append(kvl)
             inter.append(SimpleNamespace(
@@ -182,6 +183,9 @@ def test_backend_generation_trace(oracle, method, disable_evict_prefill):
     # steady state: every sequence holds between budget and budget + block tokens
     for rid in prompts:
         assert budget <= bm.get_seq_kv_len(seq_of[rid]) <= budget + BS or seq_len[rid] <= budget + BS
+    # no kernel had to clamp a length to its table or drop a block score
+    from vllm_paged_compression_amd import ops
+    ops.check_device_diagnostics()
 
 
 def test_backend_no_eviction_plain_path():
@@ -210,3 +214,184 @@ def test_backend_no_eviction_plain_path():
     # profiling run: empty cache tensor, output still produced
     out2 = impl.forward(q.cuda(), k.cuda(), v.cuda(), torch.empty(0, device="cuda", dtype=torch.float16), meta)
     torch.testing.assert_close(out2, out)
+
+
+@pytest.mark.parametrize("per_layer", [False, True])
+def test_backend_inverse_key_l2_decode_trace(oracle, per_layer):
+    """Budget-type inverse_key_l2: the prompt is pruned per head by 1/(||K||+1e-8), and every
+    decode step past the budget zeroes one random middle slot per sequence instead of removing
+    a block (torch_cuda_sdpa.py:1435-1475,962-976).  The draws come from the global ``random``
+    module seeded 1234 by the impl constructor (:796): the CPU walk replays them from
+    ``random.Random(1234)``.  per_layer=True is HEAD's order (every layer draws its own slots,
+    layer 0 first); the default draws once per step and zeroes the same slots in every layer.
+    KV cache bytes must be identical after every layer of every step."""
+    import random
+    from vllm_paged_compression_amd.backend import PagedEvictBackend
+    from vllm_paged_compression_amd.block_table import EvictBlockSpaceManager, EvictionScheduler
+    from vllm_paged_compression_amd.config import CacheConfigView, CompatFlags, PagedEvictConfig
+    from vllm_paged_compression_amd.page_evict_kv_util import adjust_seq_kv_len
+
+    g = torch.Generator().manual_seed(77)
+    Hq, Hkv, D, L_layers, nb = 8, 2, 128, 3, 96
+    budget, n_decode = 128, 36
+    cfg = PagedEvictConfig(True, "budget", "inverse_key_l2", budget, -1)
+    cache_cfg = CacheConfigView(BS, cfg)
+    compat = CompatFlags(per_layer_decision=per_layer)
+    impl_cls = PagedEvictBackend.get_impl_cls()
+    impls = [impl_cls(Hq, D, D ** -0.5, Hkv, None, None, "auto", None, None, cache_config=cache_cfg,
+                      prefix=f"model.layers.{i}.self_attn.attn", compat=compat) for i in range(L_layers)]
+    rng = random.Random(1234)   # the state the last impl constructor left the global module in
+    kv_gpu = [torch.zeros(PagedEvictBackend.get_kv_cache_shape(nb, BS, Hkv, D), dtype=torch.bfloat16,
+                          device="cuda") for _ in range(L_layers)]
+    kc_cpu = [torch.zeros(nb, Hkv, D // 8, BS, 8, dtype=torch.bfloat16) for _ in range(L_layers)]
+    vc_cpu = [torch.zeros(nb, Hkv, D, BS, dtype=torch.bfloat16) for _ in range(L_layers)]
+    sched = EvictionScheduler(EvictBlockSpaceManager(BS, nb, cfg, watermark=0.0))
+    prompts = {"r0": 200, "r1": 120, "r2": 131}     # r1 starts under the budget and crosses it
+    seq_of = {"r0": 0, "r1": 1, "r2": 2}
+    for rid, n in prompts.items():
+        sched.add_request(rid, seq_of[rid], n)
+    bm = sched.block_manager
+    inter = [SimpleNamespace(request_id=rid, is_prompt=True,
+                             block_tables={seq_of[rid]: list(bm.get_block_table(seq_of[rid]))},
+                             seq_kv_lens={seq_of[rid]: bm.get_seq_kv_len(seq_of[rid])},
+                             seq_ids=[seq_of[rid]], input_tokens=[[0] * n], orig_seq_lens=[n],
+                             seq_lens=[n], query_lens=[n], context_lens=[0])
+             for rid, n in prompts.items()]
+    lens = list(prompts.values())
+    meta = _builder(cfg, inter).build(lens, lens, -1, len(lens))
+    slot_expect = []
+    for it in inter:
+        sid = it.seq_ids[0]
+        slot_expect += oracle.prompt_slot_mapping(it.block_tables[sid], it.seq_lens[0], BS)
+    assert meta.slot_mapping.cpu().tolist() == slot_expect
+    T = sum(lens)
+    for li in range(L_layers):
+        q, k, v = _mk_inputs(T, Hq, Hkv, D, g)
+        impls[li].forward(q.cuda(), k.cuda(), v.cuda(), kv_gpu[li], meta)
+        k3, v3 = k.view(T, Hkv, D), v.view(T, Hkv, D)
+        pk, pv, off = [], [], 0
+        for n in lens:
+            a, b = oracle.prompt_prune(k3[off:off + n], v3[off:off + n], "inverse_key_l2", budget, BS)
+            pk.append(a)
+            pv.append(b)
+            off += n
+        oracle.reshape_and_cache(torch.cat(pk), torch.cat(pv), kc_cpu[li], vc_cpu[li],
+                                 torch.tensor(slot_expect))
+        assert torch.equal(kv_gpu[li][0].view_as(kc_cpu[li]).cpu(), kc_cpu[li])
+        assert torch.equal(kv_gpu[li][1].view_as(vc_cpu[li]).cpu(), vc_cpu[li])
+
+    seq_len = dict(zip(prompts.keys(), lens))
+    n_zeroed = 0
+    for step in range(n_decode):
+        tables, kv_lens = sched.schedule_decode(list(prompts.keys()))
+        inter, logical, kv_adj = [], [], []
+        for rid in prompts:
+            sid = seq_of[rid]
+            seq_len[rid] += 1
+            L = seq_len[rid]
+            kvl = adjust_seq_kv_len(cfg, L, kv_lens[sid], BS)
+            assert kvl == kv_lens[sid]      # this method never shortens the attention view
+            logical.append(L)
+            kv_adj.append(kvl)
+            inter.append(SimpleNamespace(
+                request_id=rid, is_prompt=False, block_tables={sid: list(tables[sid])},
+                seq_kv_lens={sid: kvl}, seq_ids=[sid], input_tokens=[[0]], orig_seq_lens=[L],
+                seq_lens=[L], query_lens=[1], context_lens=[kv_lens[sid] - 1]))
+        meta = _builder(cfg, inter).build(logical, [1] * 3, -1, 3)
+        tbls = [list(tables[seq_of[r]]) for r in prompts]
+        slots = [oracle.decode_slot(t, kv_lens[seq_of[r]] - 1, BS) for t, r in zip(tbls, prompts)]
+        assert meta.slot_mapping.cpu().tolist() == slots
+        M = max(len(t) for t in tbls)
+        bt = torch.zeros((3, M), dtype=torch.int32)
+        for i, t in enumerate(tbls):
+            bt[i, :len(t)] = torch.tensor(t)
+        zero_step = None
+        for li in range(L_layers):
+            if per_layer or zero_step is None:
+                zero_step = oracle.decode_inverse_key_l2(logical, tbls, budget, BS, rng)
+            q, k, v = _mk_inputs(3, Hq, Hkv, D, g)
+            out = impls[li].forward(q.cuda(), k.cuda(), v.cuda(), kv_gpu[li], meta)
+            oracle.reshape_and_cache(k.view(3, Hkv, D), v.view(3, Hkv, D), kc_cpu[li], vc_cpu[li],
+                                     torch.tensor(slots))
+            if zero_step:
+                z = torch.zeros(len(zero_step), Hkv, D, dtype=torch.bfloat16)
+                oracle.reshape_and_cache(z, z, kc_cpu[li], vc_cpu[li], torch.tensor(zero_step))
+                n_zeroed += len(zero_step)
+            assert torch.equal(kv_gpu[li][0].view_as(kc_cpu[li]).cpu(), kc_cpu[li]), (step, li)
+            assert torch.equal(kv_gpu[li][1].view_as(vc_cpu[li]).cpu(), vc_cpu[li]), (step, li)
+            ref = oracle.paged_attention(q.view(3, Hq, D), kc_cpu[li], vc_cpu[li], bt,
+                                         torch.tensor(kv_adj, dtype=torch.int32), D ** -0.5)
+            torch.testing.assert_close(out.cpu().float().view(3, Hq, D), ref.float(), atol=2e-3,
+                                       rtol=1.6e-2, msg=lambda m: f"step {step} layer {li}: {m}")
+        assert impls[0].get_rmv_block_idx() == {}      # nothing to commit: no block leaves
+        sched.commit(impls[0].get_rmv_block_idx())
+        for i, rid in enumerate(prompts):
+            assert bm.get_block_table(seq_of[rid]) == tbls[i]
+    assert n_zeroed >= 2 * n_decode
+
+
+@pytest.mark.parametrize("head_compat", [False, True])
+def test_streaming_decode_table_on_eviction_steps(oracle, head_compat):
+    """On a streamingLLM eviction step the default attends the compacted table; HEAD builds that
+    table and then ignores it (the flag it sets, is_pruned_decode at torch_cuda_sdpa.py:903-911,
+    is not the one the attention call tests, is_prune_decode at :858,1046), reading the ORIGINAL
+    table with the kv length shortened by one block.  CompatFlags.streaming_decode_original_table
+    reproduces that; the committed victim is block 1 either way."""
+    from vllm_paged_compression_amd.backend import PagedEvictBackend
+    from vllm_paged_compression_amd.block_table import EvictBlockSpaceManager, EvictionScheduler
+    from vllm_paged_compression_amd.config import CacheConfigView, CompatFlags, PagedEvictConfig
+    from vllm_paged_compression_amd.page_evict_kv_util import adjust_seq_kv_len
+    g = torch.Generator().manual_seed(5)
+    Hq, Hkv, D, nb, budget, n = 8, 2, 128, 40, 128, 150
+    cfg = PagedEvictConfig(True, "budget", "streamingLLM", budget, -1)
+    impls = [PagedEvictBackend.get_impl_cls()(
+        Hq, D, D ** -0.5, Hkv, None, None, "auto", None, None, cache_config=CacheConfigView(BS, cfg),
+        prefix=f"model.layers.{i}.self_attn.attn",
+        compat=CompatFlags(streaming_decode_original_table=head_compat)) for i in range(2)]
+    kv_gpu = [torch.zeros(PagedEvictBackend.get_kv_cache_shape(nb, BS, Hkv, D), dtype=torch.bfloat16,
+                          device="cuda") for _ in impls]
+    kc = [torch.zeros(nb, Hkv, D // 8, BS, 8, dtype=torch.bfloat16) for _ in impls]
+    vc = [torch.zeros(nb, Hkv, D, BS, dtype=torch.bfloat16) for _ in impls]
+    sched = EvictionScheduler(EvictBlockSpaceManager(BS, nb, cfg, watermark=0.0))
+    sched.add_request("r", 0, n)
+    bm = sched.block_manager
+    table = list(bm.get_block_table(0))
+    meta = _builder(cfg, [SimpleNamespace(
+        request_id="r", is_prompt=True, block_tables={0: table}, seq_kv_lens={0: bm.get_seq_kv_len(0)},
+        seq_ids=[0], input_tokens=[[0] * n], orig_seq_lens=[n], seq_lens=[n], query_lens=[n],
+        context_lens=[0])]).build([n], [n], -1, 1)
+    for li, impl in enumerate(impls):
+        q, k, v = _mk_inputs(n, Hq, Hkv, D, g)
+        impl.forward(q.cuda(), k.cuda(), v.cuda(), kv_gpu[li], meta)
+        pk, pv = oracle.prompt_prune(k.view(n, Hkv, D), v.view(n, Hkv, D), "streamingLLM", budget, BS)
+        oracle.reshape_and_cache(pk, pv, kc[li], vc[li], torch.tensor(oracle.prompt_slot_mapping(table, n, BS)))
+    L, evictions = n, 0
+    for _ in range(30):
+        tables, kvl = sched.schedule_decode(["r"])
+        L += 1
+        table = list(tables[0])
+        kv_len = adjust_seq_kv_len(cfg, L, kvl[0], BS)
+        meta = _builder(cfg, [SimpleNamespace(
+            request_id="r", is_prompt=False, block_tables={0: table}, seq_kv_lens={0: kv_len}, seq_ids=[0],
+            input_tokens=[[0]], orig_seq_lens=[L], seq_lens=[L], query_lens=[1],
+            context_lens=[kvl[0] - 1])]).build([L], [1], -1, 1)
+        rmv, _ = oracle.decode_streaming([L], [table], budget, BS, "streamingLLM")
+        bt = torch.tensor([table], dtype=torch.int32)
+        use = bt
+        if rmv[0] >= 0 and not head_compat:
+            use = oracle.compact_block_tables(bt, rmv, out_width=len(table) - 1)
+        for li, impl in enumerate(impls):
+            q, k, v = _mk_inputs(1, Hq, Hkv, D, g)
+            out = impl.forward(q.cuda(), k.cuda(), v.cuda(), kv_gpu[li], meta)
+            oracle.reshape_and_cache(k.view(1, Hkv, D), v.view(1, Hkv, D), kc[li], vc[li],
+                                     torch.tensor([oracle.decode_slot(table, kvl[0] - 1, BS)]))
+            assert torch.equal(kv_gpu[li][0].view_as(kc[li]).cpu(), kc[li])
+            assert torch.equal(kv_gpu[li][1].view_as(vc[li]).cpu(), vc[li])
+            ref = oracle.paged_attention(q.view(1, Hq, D), kc[li], vc[li], use,
+                                         torch.tensor([kv_len], dtype=torch.int32), D ** -0.5)
+            torch.testing.assert_close(out.cpu().float().view(1, Hq, D), ref.float(), atol=2e-3, rtol=1.6e-2)
+        got = impls[0].get_rmv_block_idx()
+        assert got == ({0: ("r", 1)} if rmv[0] >= 0 else {})
+        evictions += len(got)
+        sched.commit(got)
+    assert evictions == 2

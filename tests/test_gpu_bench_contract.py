@@ -31,3 +31,50 @@ def test_bench_json_line(extra):
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and 0 < r["frac"] < 1
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert d["config"]["kv_gb_saved"] >= 0
+
+
+def test_bench_gpus_2_starts_two_ranks():
+    """`python bench.py --gpus 2` with no launcher around it must start two ranks itself (here
+    both on the one test GPU, collectives through gloo) and label the line n_gpus = 2; a
+    launcher that started a different number of ranks than --gpus says is an error."""
+    env = dict(os.environ, PE_BENCH_DIST_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--num-prompts", "4", "--prefill-batch", "2", "--output-len", "24", "--layers", "3",
+           "--no-cpu-baseline", "--alt-evict", "0"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=280, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    c = d["config"]
+    assert c["world_size"] == 2 and c["parallelism"] == "tp2" and c["dist_backend"] == "gloo"
+    assert len(c["devices"]) == 2
+    assert "8 requests" in c["workload"]          # weak scaling: 2 x 4 requests over half the heads each
+    assert c["tp_strong"]["requests"] == 4 and c["tp_strong"]["value"] > 0
+    # WORLD_SIZE that contradicts --gpus
+    env1 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    bad = subprocess.run(cmd, capture_output=True, text=True, timeout=120, cwd=ROOT, env=env1)
+    assert bad.returncode != 0 and "WORLD_SIZE=1" in (bad.stderr + bad.stdout)
+
+
+def test_bench_presets_select_the_baseline_configs():
+    """--config cN maps to the shapes BASELINE.json names (checked on shrunken runs)."""
+    def run(*flags):
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0",
+               "--no-cpu-baseline", *flags]
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=280, cwd=ROOT)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    d = run("--config", "c1", "--output-len", "8")
+    assert "OPT-125m" in d["config"]["workload"] and "no eviction" in d["config"]["workload"]
+    assert d["dtype"] == "fp16" and "1 requests 1024->8" in d["config"]["workload"]
+    d = run("--config", "c3", "--num-prompts", "2", "--prefill-batch", "2", "--output-len", "20", "--layers", "2")
+    assert "8192->20" in d["config"]["workload"] and "budget 4096 (50% eviction)" in d["config"]["workload"]
+    assert d["roofline_prefill"]["bound"] == "mfma" and 0 < d["roofline_prefill"]["frac"] < 1
+    d = run("--config", "c4", "--emulate-tp", "8", "--num-prompts", "2", "--prefill-batch", "2",
+            "--output-len", "20", "--layers", "2")
+    assert "Hq 64, Hkv 8" in d["config"]["workload"] and "TP=8" in d["config"]["workload"]
+    assert "budget 3072 (25% eviction)" in d["config"]["workload"]

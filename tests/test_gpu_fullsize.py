@@ -87,8 +87,25 @@ def test_decode_full_size_properties(ops, oracle, B, kv_lo, kv_hi, Hq, Hkv, D, d
     torch.testing.assert_close(oc, want, atol=8e-3, rtol=8e-3)   # one bf16 rounding of P and of O
 
 
-def test_prefill_full_size_properties(ops, oracle):
-    Hq, Hkv, D, L = 32, 8, 128, 8192
+def _rows_f32(q, k, v, rows, sc, Lkv=None):
+    """f32 attention of single query rows (top-left causal: row i sees kv rows 0..min(i, Lkv-1))."""
+    Hq, Hkv = q.shape[1], k.shape[1]
+    outs = []
+    for i in rows:
+        n = i + 1 if Lkv is None else min(i + 1, Lkv)
+        kk = k[:n].float().repeat_interleave(Hq // Hkv, dim=1)     # [n, Hq, D]
+        vv = v[:n].float().repeat_interleave(Hq // Hkv, dim=1)
+        s = torch.einsum("hd,nhd->hn", q[i].float(), kk) * sc
+        outs.append(torch.einsum("hn,nhd->hd", torch.softmax(s, dim=-1), vv))
+    return torch.stack(outs)
+
+
+@pytest.mark.parametrize("Hq,Hkv,L,Lkv,label", [
+    (32, 8, 8192, 4096, "8B 8192->1024 at 50%"),
+    (32, 8, 32768, 16384, "8B 32768->2048 at 50%: one launch, 256 query tiles"),
+    (8, 1, 4096, 3072, "70B TP=8, one rank's heads, 4096->512 at 25%")])
+def test_prefill_full_size_properties(ops, oracle, Hq, Hkv, L, Lkv, label):
+    D = 128
     dt = torch.bfloat16
     g = torch.Generator(device="cuda").manual_seed(8)
     sc = D ** -0.5
@@ -102,14 +119,20 @@ def test_prefill_full_size_properties(ops, oracle):
     n = 200
     ref = oracle.prefill_attention(q[:n].cpu().float(), k[:n].cpu().float(), v[:n].cpu().float(), [n], [n], sc)
     torch.testing.assert_close(out[:n].cpu().float(), ref, atol=2e-2, rtol=1.6e-2)
+    # rows sampled over the whole length (tile boundaries, the last rows) against f32 attention
+    rows = sorted({63, 64, 127, 128, 1000, L // 3, L // 2 - 1, L // 2, L - 130, L - 65, L - 64, L - 2, L - 1})
+    # (outputs of late rows are means over thousands of values, |o| ~ 1e-2: the absolute bar is the
+    # decode kernel test's, not the 2e-2 of the short-prompt comparison)
+    torch.testing.assert_close(out[rows].float(), _rows_f32(q, k, v, rows, sc), atol=2e-3, rtol=1.6e-2)
     # causality: changing K/V rows > j leaves rows <= j bit-identical
-    j = 5000
+    j = (5 * L) // 8 + 8
     k2, v2 = k.clone(), v.clone()
     k2[j + 1:].uniform_(-3, 3, generator=g)
     v2[j + 1:].uniform_(-3, 3, generator=g)
     out2 = ops.prefill_causal(q, k2, v2, cu, cu, L, sc)
     assert torch.equal(out2[:j + 1], out[:j + 1])
     assert not torch.equal(out2[j + 1:], out[j + 1:])
+    del k2, v2, out2
     # last row == decode attention of that query over the paged copy of the same K/V
     nblk = L // BS
     kc = torch.zeros(nblk + 2, Hkv, D // 8, BS, 8, dtype=dt, device="cuda")
@@ -121,14 +144,45 @@ def test_prefill_full_size_properties(ops, oracle):
                   torch.tensor([L], dtype=torch.int32, device="cuda"), L)
     torch.testing.assert_close(dec[0].float(), out[L - 1].float(), atol=2e-3, rtol=1.6e-2)
     # pruned-before-attention form (L_kv < L_q, top-left mask): rows < L_kv see the same prefix
-    Lkv = 4096
     cu_kv = torch.tensor([0, Lkv], dtype=torch.int32, device="cuda")
     outp = ops.prefill_causal(q, k[:Lkv].contiguous(), v[:Lkv].contiguous(), cu, cu_kv, L, sc)
     assert torch.equal(outp[:Lkv], out[:Lkv])
-    # rows >= L_kv all attend the whole pruned K/V: the last one equals decode over 4096 tokens
+    rows = sorted({Lkv, Lkv + 63, (L + Lkv) // 2, L - 1})
+    torch.testing.assert_close(outp[rows].float(), _rows_f32(q, k, v, rows, sc, Lkv), atol=2e-3, rtol=1.6e-2)
+    # rows >= L_kv all attend the whole pruned K/V: the last one equals decode over L_kv tokens
     dec2 = _decode(ops, q[L - 1:L].contiguous(), kc, vc, table[:Lkv // BS].unsqueeze(0).contiguous(),
                    torch.tensor([Lkv], dtype=torch.int32, device="cuda"), Lkv)
     torch.testing.assert_close(dec2[0].float(), outp[L - 1].float(), atol=2e-3, rtol=1.6e-2)
+
+
+def test_prefill_batch_64x8192(ops):
+    """One launch over the whole batch of the 8192->1024 configuration (64 prompts of 8192 tokens,
+    524,288 query rows): every request holds the same data, so every request's output must be
+    bit-identical to the single-request launch (no dependence on the position in the batch), and
+    a request with different data in the middle of the batch must not disturb its neighbours."""
+    Hq, Hkv, D, L, B = 32, 8, 128, 8192, 64
+    dt = torch.bfloat16
+    sc = D ** -0.5
+    g = torch.Generator(device="cuda").manual_seed(15)
+    q1 = torch.empty(L, Hq, D, dtype=dt, device="cuda").uniform_(-1, 1, generator=g)
+    k1 = torch.empty(L, Hkv, D, dtype=dt, device="cuda").uniform_(-1, 1, generator=g)
+    v1 = torch.empty(L, Hkv, D, dtype=dt, device="cuda").uniform_(-1, 1, generator=g)
+    cu1 = torch.tensor([0, L], dtype=torch.int32, device="cuda")
+    single = ops.prefill_causal(q1, k1, v1, cu1, cu1, L, sc)
+    q = q1.repeat(B, 1, 1)
+    k = k1.repeat(B, 1, 1)
+    v = v1.repeat(B, 1, 1)
+    odd = 37
+    k[odd * L:(odd + 1) * L].uniform_(-1, 1, generator=g)
+    cu = torch.arange(0, B + 1, dtype=torch.int32, device="cuda") * L
+    out = ops.prefill_causal(q, k, v, cu, cu, L, sc).view(B, L, Hq, D)
+    for b in range(B):
+        if b == odd:
+            assert not torch.equal(out[b], single)
+        else:
+            assert torch.equal(out[b], single), f"request {b} differs from the single-request launch"
+    lone = ops.prefill_causal(q1, k[odd * L:(odd + 1) * L], v1, cu1, cu1, L, sc)
+    assert torch.equal(out[odd], lone)
 
 
 def test_kv_write_round_trip_full_size(ops):

@@ -151,9 +151,14 @@ def test_continuous_batching_fuzz(oracle, method, seed, evict_before_prefill, ve
                     kv_adj.append(kv_lens[sid] - (n_rm * BS if first >= 0 else 0))
                 else:
                     kv_adj.append(kv_lens[sid] - (BS if oracle.decode_trigger(logical[rid], BUDGET, BS) else 0))
+            # what attention must see this step comes from the package (the model runner's
+            # adjustment, model_runner.py:538-543); the oracle's figures above are the check
+            from vllm_paged_compression_amd.page_evict_kv_util import adjust_seq_kv_len
+            assert kv_adj == [adjust_seq_kv_len(cfg, logical[rid], kv_lens[seq_of[rid]], BS)
+                              for rid in running]
             if batch is not None:
-                import numpy as np
-                meta = builder([]).build_decode_batch(batch, np.asarray(kv_adj))
+                meta = builder([]).build_decode_batch(batch)
+                assert meta.seq_kv_lens == kv_adj
             else:
                 inter = [SimpleNamespace(request_id=rid, is_prompt=False,
                                          block_tables={seq_of[rid]: list(tables[seq_of[rid]])},
@@ -231,4 +236,6 @@ def test_continuous_batching_fuzz(oracle, method, seed, evict_before_prefill, ve
         step += 1
         assert step < 2000
     assert n_prefills >= 3 and n_evictions >= 4, (n_prefills, n_evictions)
+    from vllm_paged_compression_amd import ops
+    ops.check_device_diagnostics()   # nothing was clamped or dropped on the way
     assert bm.get_num_free_gpu_blocks() == nb

@@ -736,3 +736,44 @@ def test_rope_reshape_and_cache(ops, oracle, dtype, is_neox, Hq, Hkv, D, rot):
     assert torch.equal(q2, qd) and torch.equal(k2, kd)
     # empty batch
     ops.rotary_embedding(pos[:0].cuda(), q2[:0], k2[:0], D, cs.cuda(), is_neox)
+
+
+def test_device_diagnostics_report_clamps(oracle):
+    """A seq_lens entry beyond the block-table row and a full score row are survived by clamping;
+    both must be visible through pe_device_diagnostics (and cleared by reading with reset)."""
+    from vllm_paged_compression_amd import ops
+    assert ops.device_diagnostics(reset=True) in (0, 1, 2, 3)      # clear whatever earlier tests left
+    assert ops.device_diagnostics(reset=False) == 0
+    g = torch.Generator().manual_seed(2)
+    Hq, Hkv, D, nb, M = 8, 2, 128, 16, 4
+    kc = torch.rand(nb, Hkv, D // 8, 16, 8, generator=g).to(torch.bfloat16).cuda()
+    vc = torch.rand(nb, Hkv, D, 16, generator=g).to(torch.bfloat16).cuda()
+    q = torch.rand(2, Hq, D, generator=g).to(torch.bfloat16).cuda()
+    bt = torch.arange(8, dtype=torch.int32).reshape(2, M).cuda()
+    out = torch.empty_like(q)
+    ok_lens = torch.tensor([64, 10], dtype=torch.int32).cuda()
+    ops.paged_attention_v1(out, q, kc, vc, Hkv, D ** -0.5, bt, ok_lens, 16, 64, None)
+    assert ops.device_diagnostics(reset=False) == 0
+    bad_lens = torch.tensor([64, 65], dtype=torch.int32).cuda()       # 65 > 4 blocks x 16
+    ops.paged_attention_v1(out, q, kc, vc, Hkv, D ** -0.5, bt, bad_lens, 16, 65, None)
+    assert ops.device_diagnostics(reset=False) == ops.DIAG_DECODE_LEN_CLAMPED
+    with pytest.raises(RuntimeError, match="beyond its block-table row"):
+        ops.check_device_diagnostics()
+    assert ops.device_diagnostics(reset=False) == 0
+    # clamped result == result at the table's capacity
+    ref = oracle.paged_attention(q.cpu(), kc.cpu(), vc.cpu(), bt.cpu(), torch.tensor([64, 64]), D ** -0.5)
+    torch.testing.assert_close(out.cpu().float(), ref.float(), atol=1e-3, rtol=1.6e-2)
+    # score row of width 4 already holding 4 scores: the 5th is dropped and flagged
+    width = 4
+    table = torch.tensor([[3.0, 1.0, 2.0, 5.0]], dtype=torch.float32).cuda()
+    counts = torch.tensor([4], dtype=torch.int32).cuda()
+    rows = torch.tensor([0], dtype=torch.int32).cuda()
+    bt1 = torch.arange(10, dtype=torch.int32).reshape(1, 10).cuda()
+    rmv, tabs, _ = ops.evict_select_compact(
+        bt1, torch.tensor([160], dtype=torch.int32).cuda(), torch.tensor([10], dtype=torch.int32).cuda(),
+        "global", 128, 16, score_table=table, score_counts=counts, score_rows=rows, value_cache=vc[:, :, :, :],
+        out_width=9)
+    assert width == table.shape[1]
+    assert ops.device_diagnostics(reset=True) == ops.DIAG_SCORE_ROW_FULL
+    assert int(rmv[0]) == 1          # arg-min over [1, n-1) of the stored scores
+    ops.check_device_diagnostics()   # clean again

@@ -46,7 +46,7 @@ def run_trace(rank, world, group, mode="budget"):
     from vllm_paged_compression_amd.config import CacheConfigView, PagedEvictConfig
     dev = torch.device("cuda:0")
     sh = parallel.shard_heads(HQ, HKV, world, rank)
-    from vllm_paged_compression_amd.page_evict_kv_util import percentage_decode_trigger
+    from vllm_paged_compression_amd.page_evict_kv_util import adjust_seq_kv_len
     if mode == "percentage":
         cfg = PagedEvictConfig(True, "percentage", "streamingLLM", 0, -1, evict_freq=2,
                                num_block_merge=2, decode_evict_method="value_l2")
@@ -99,10 +99,7 @@ def run_trace(rank, world, group, mode="budget"):
             sid = seq_of[rid]
             seq_len[rid] += 1
             L = seq_len[rid]
-            if mode == "percentage":
-                kvl = kv_lens[sid] - (BS if percentage_decode_trigger(cfg, L, kv_lens[sid], BS) else 0)
-            else:
-                kvl = kv_lens[sid] - (BS if (L > BUDGET and L % BS == 0) else 0)
+            kvl = adjust_seq_kv_len(cfg, L, kv_lens[sid], BS)
             logical.append(L)
             inter.append(SimpleNamespace(request_id=rid, is_prompt=False,
                                          block_tables={sid: list(tables[sid])}, seq_kv_lens={sid: kvl},

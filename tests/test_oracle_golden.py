@@ -238,3 +238,35 @@ def test_rotary_embedding_oracle_matches_native_form(oracle, dtype, is_neox, H, 
         torch.testing.assert_close(got, want, atol=1e-6, rtol=1e-6)   # a*b-c*d: no rounding contract
     else:
         assert torch.equal(got, want)
+
+
+def test_ref_cpu_rope_golden(oracle):
+    """oracle.rotary_embedding against outputs of the reference's CPU kernel
+    (csrc/cpu/pos_encoding.cpp, compiled in place; fixture from tests/golden/make_golden.py).
+    The oracle follows the CUDA kernel (csrc/pos_encoding_kernels.cu:10-35), whose arithmetic
+    runs in the storage type: both products and their sum are each rounded; the CPU kernel
+    computes in f32 and rounds once (pos_encoding.cpp:44-54).  The two therefore agree to a
+    couple of units in the last place of the storage type, exactly in f32 - which is the bar
+    here; the per-operation rounding itself is pinned by no artefact of the reference."""
+    z = np.load(os.path.join(GOLDEN, "ref_cpu_rope.npz"))
+    n = len([k for k in z.files if k.endswith("_meta")])
+    assert n == 5
+    for c in range(n):
+        Hq, Hkv, D, rot, neox, dt = [int(v) for v in z[f"c{c}_meta"]]
+        pos = torch.from_numpy(z[f"c{c}_pos"])
+        cache = from_bits(z[f"c{c}_cache"], dt)
+        assert cache.shape[1] == rot
+        for name, H in (("q", Hq), ("k", Hkv)):
+            x = from_bits(z[f"c{c}_{name}_in"], dt)
+            want = from_bits(z[f"c{c}_{name}_out"], dt)
+            got = oracle.rotary_embedding(pos, x, D, cache, bool(neox))
+            assert got.shape == want.shape == (pos.numel(), H * D)
+            # |values| <= 2*sqrt(2): two units in the last place of the storage type at that size
+            atol = {0: 1e-6, 1: 4e-3, 2: 3.2e-2}[dt]
+            torch.testing.assert_close(got.float(), want.float(), atol=atol, rtol=0)
+            # the columns past rot_dim of every head pass through untouched
+            if rot < D:
+                g3, x3 = got.view(-1, H, D), x.view(-1, H, D)
+                assert torch.equal(g3[:, :, rot:], x3[:, :, rot:])
+            # and a rotation really happened (positions are mostly non-zero)
+            assert not torch.equal(got, x)

@@ -68,3 +68,26 @@ def test_copy_blocks_exact(oracle, ref):
     oracle.copy_blocks(kc, vc, mapping)
     ref.copy_blocks([kc2], [vc2], mapping)
     assert torch.equal(kc, kc2) and torch.equal(vc, vc2)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("neox", [True, False])
+@pytest.mark.parametrize("Hq,Hkv,D,rot", [(32, 8, 128, 128), (12, 12, 64, 64), (8, 1, 128, 64)])
+def test_rotary_embedding_close(oracle, ref, dtype, neox, Hq, Hkv, D, rot):
+    """oracle.rotary_embedding (storage-type arithmetic of csrc/pos_encoding_kernels.cu:10-35)
+    against the reference's CPU kernel (f32 arithmetic, one rounding, csrc/cpu/pos_encoding.cpp):
+    within two units in the last place of the storage type."""
+    g = torch.Generator().manual_seed(11)
+    T, max_pos = 67, 4096
+    inv_freq = 1.0 / (10000.0 ** (torch.arange(0, rot, 2, dtype=torch.float) / rot))
+    freqs = torch.einsum("i,j -> ij", torch.arange(max_pos, dtype=torch.float), inv_freq)
+    cache = torch.cat((freqs.cos(), freqs.sin()), dim=-1).to(dtype)
+    qkv = ((torch.rand(T, (Hq + 2 * Hkv) * D, generator=g) * 2 - 1) * 2).to(dtype)
+    pos = torch.randint(0, max_pos, (T,), generator=g, dtype=torch.int64)
+    q, k = qkv[:, :Hq * D], qkv[:, Hq * D:(Hq + Hkv) * D]
+    got_q = oracle.rotary_embedding(pos, q, D, cache, neox)
+    got_k = oracle.rotary_embedding(pos, k, D, cache, neox)
+    ref.rotary_embedding(pos, q, k, D, cache, neox)      # in place on the fused buffer's views
+    atol = {torch.float32: 1e-6, torch.float16: 4e-3, torch.bfloat16: 3.2e-2}[dtype]
+    torch.testing.assert_close(got_q.float(), q.float(), atol=atol, rtol=0)
+    torch.testing.assert_close(got_k.float(), k.float(), atol=atol, rtol=0)

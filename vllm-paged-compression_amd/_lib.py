@@ -16,6 +16,7 @@ PE_F32, PE_F16, PE_BF16 = 0, 1, 2
 SIGNATURES = {
     "pe_last_error": (ctypes.c_char_p, []),
     "pe_version": (c_int, []),
+    "pe_device_diagnostics": (c_int, [c_void_p, c_int]),
     "pe_reshape_and_cache": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                      c_int64, c_int64, c_void_p, c_int, c_void_p, c_int64, c_int,
                                      c_int, c_int, c_int64, c_int, c_void_p]),

@@ -30,6 +30,7 @@ import torch
 from . import ops, parallel, staging
 from .block_l2norm_manager import BlockL2NormManager
 from .config import CompatFlags, PagedEvictConfig
+from .page_evict_kv_util import adjust_seq_kv_lens
 from .paged_attn import PagedAttention
 from .pruner import KVCachePruner
 
@@ -337,12 +338,15 @@ class PagedEvictMetadataBuilder(_BuilderBase):
             reqid_mapping_blocktables=self.reqid_mapping_blocktables)
 
 
-    def build_decode_batch(self, batch, seq_kv_lens) -> PagedEvictMetadata:
+    def build_decode_batch(self, batch, seq_kv_lens=None) -> PagedEvictMetadata:
         """Metadata of a pure decode step straight from a ``batch_scheduler.DecodeBatch`` - the
         same fields ``build`` derives sequence by sequence, computed with array operations.
-        ``seq_kv_lens``: the physical lengths attention reads (``batch.kv_lens``, minus a block
-        on the steps that evict, as the model runner adjusts them, model_runner.py:538-543)."""
+        ``seq_kv_lens``: the physical lengths attention reads; by default ``batch.kv_lens`` minus
+        what this step evicts, the adjustment the model runner makes before attention
+        (model_runner.py:538-543, ``page_evict_kv_util.adjust_seq_kv_lens``)."""
         bs = self.block_size
+        if seq_kv_lens is None:
+            seq_kv_lens = adjust_seq_kv_lens(self.paged_evict_config, batch.seq_lens, batch.kv_lens, bs)
         B = len(batch.request_ids)
         device = self.runner.device
         i32 = np.int32
@@ -741,6 +745,11 @@ class PagedEvictImpl(_ImplBase):
                                                    self.head_size, dm.slot_mapping, zero_slots,
                                                    block_tables, seq_lens_arg, max_len, self.scale)
                 launcher.tables, launcher.zero = block_tables, zero_slots
+                if self.compat.streaming_decode_original_table:
+                    # HEAD reads kv_len tokens of the ORIGINAL table, which leaves the step's own
+                    # token out: the fused launch (new token attended from registers) cannot
+                    # express that
+                    launcher.fused = False
             except RuntimeError:
                 launcher = None  # shape outside the launcher's contract: per-op path below
             step["launcher"] = launcher
@@ -819,6 +828,8 @@ class PagedEvictImpl(_ImplBase):
                     cfg.cache_budget, bs, compat_q1=self.compat.block_table_slice_in_loop,
                     compact=any_trig, out_width=width)
                 dec["tables"] = tables if any_trig else None
+                if self.compat.streaming_decode_original_table:
+                    dec["tables"] = None   # HEAD: the compacted table is built and then ignored
                 dec["zero_slots"] = zero
                 dec["host_rmv"] = {i: (req_ids[i], 1) for i, t in enumerate(trig) if t}
         elif any_trig:

@@ -84,6 +84,16 @@ class PagedEvictConfig:
             logger.warning("Cache budget is set to less than 128 tokens. "
                            "Setting cache budget to 128 tokens.")
             self.cache_budget = 128
+        if self.cache_budget % 16 != 0:
+            # every block size the backend runs (8, 16, 32 in the reference's scripts) divides a
+            # multiple of 16 only if it is <= 16; KVCachePruner re-checks against the real block
+            # size.  A budget that is not a whole number of blocks makes the pruned-length formula
+            # return more tokens than a prompt just above the budget has
+            # (vllm/attention/kvcache_prunner.py:284-326; the reference then fails in copy_)
+            rounded = self.cache_budget // 16 * 16
+            logger.warning("Cache budget %d is not a multiple of 16; using %d.", self.cache_budget,
+                           rounded)
+            self.cache_budget = rounded
         if self.evict_method == "local" and self.topk_blocks <= 1:
             raise ValueError("Topk blocks must be > 1 when using 'local' evict method. "
                              f"Got {self.topk_blocks}.")
@@ -131,10 +141,16 @@ class CompatFlags:
     # index i to the i-th sequence of the step's own metadata and keeps scores until a request
     # is absent from a decode step
     request_order_first_seen: bool = False
+    # streamingLLM / streamingLLM-1 decode at HEAD computes the compacted table but never uses it:
+    # the flag it sets (is_pruned_decode, torch_cuda_sdpa.py:903-911) is not the one the attention
+    # call tests (is_prune_decode, :858,1046), so attention reads the ORIGINAL table with the kv
+    # length shortened by one block - the victim block stays visible and the last block (with
+    # the step's own token) is cut off.  The default attends the compacted table.
+    streaming_decode_original_table: bool = False
 
     @classmethod
     def reference_head(cls) -> "CompatFlags":
-        return cls(True, True, True, True, True, True, True)
+        return cls(True, True, True, True, True, True, True, True)
 
 
 @dataclass

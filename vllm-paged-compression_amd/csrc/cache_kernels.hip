@@ -226,7 +226,16 @@ __global__ void copy_blocks_kernel(void* const* __restrict__ key_ptrs,
 extern "C" {
 
 const char* pe_last_error(void) { return pe::g_last_error; }
-int pe_version(void) { return 101; }  // 101: percentage prune type entry points
+int pe_version(void) { return 102; }  // 102: pe_paged_decode_noalloc, pe_device_diagnostics
+
+int pe_device_diagnostics(unsigned int* flags_out, int reset) {
+  PE_REQUIRE(flags_out != nullptr, PE_ERR_INVALID_ARG, "device_diagnostics: null pointer");
+  unsigned int a = 0, b = 0;
+  if (int rc = pe::decode_diag_fetch(&a, reset)) return rc;
+  if (int rc = pe::evict_diag_fetch(&b, reset)) return rc;
+  *flags_out = a | b;
+  return PE_OK;
+}
 
 int pe_reshape_and_cache(const void* key, const void* value, void* key_cache, void* value_cache,
                          const int64_t* slot_mapping, int64_t num_tokens, int64_t key_stride,

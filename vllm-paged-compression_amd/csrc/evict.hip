@@ -11,56 +11,129 @@
 namespace pe {
 
 constexpr int SCORE_MAX_PAIRS = 64 * 64;  // block_size * num_kv_heads held in LDS
+constexpr int SCORE_THREADS = 256;         // workgroup of the scoring kernels
+constexpr int SCORE_STAGE_BYTES = 32 * 1024;  // LDS staging area for paged value slabs
 
-// Score of one block, computed by one wave.  Follows torch's evaluation of
-//   norm(V, dim=-1).mean(dim=1).sum(dim=0)
-// on a low-precision tensor: every reduction accumulates in f32 and its result is rounded
-// to the storage type.  The sum of squares runs over d in ascending order in one lane
-// (products of 16-bit values are exact in f32, so only this order matters).
+// Set when a sequence's score row is full and a new score could not be appended (the caller
+// sized the table too narrow); read back through pe_device_diagnostics.
+static __device__ unsigned int evict_diag_word;
+
+// LDS the scoring code needs: norms[bs*H] + means[bs] (f32) + the staging area of the paged
+// layout (whole head slabs, each padded by one row of block_size elements).
+__host__ __device__ inline int score_heads_per_pass(int num_kv_heads, int head_size, int block_size,
+                                                    int elem) {
+  const int slab = (head_size * block_size + block_size) * elem;
+  int g = SCORE_STAGE_BYTES / slab;
+  if (g > num_kv_heads) g = num_kv_heads;
+  return g;  // 0: a slab does not fit, the strided path is used
+}
+inline size_t score_lds_bytes(int layout, int num_kv_heads, int head_size, int block_size, int elem) {
+  size_t n = (size_t)(block_size * num_kv_heads + block_size) * 4;
+  n = (n + 15) & ~(size_t)15;
+  if (layout == PE_SCORE_CACHE) {
+    const int g = score_heads_per_pass(num_kv_heads, head_size, block_size, elem);
+    n += (size_t)g * (head_size * block_size + block_size) * elem;
+  }
+  return n;
+}
+
+// norms[t*H + h] = ||V[t, h, :]||_2 rounded to the storage type, for one block, computed by the
+// whole workgroup.  The sum of squares of a (token, head) pair runs over d in ascending order
+// in one thread (products of 16-bit values are exact in f32, so only this order matters) -
+// that is torch's result for norm(V, dim=-1) on a low-precision tensor.
+//   PE_SCORE_CACHE: the block is [H][D][bs]; whole head slabs are copied to LDS with 16-byte
+//   loads (a slab is contiguous, so the copy is fully coalesced) and each thread then walks
+//   the d axis of its pair in LDS - consecutive threads hold consecutive tokens, the slabs are
+//   padded by one row so that the heads of a wave fall into different banks.
+//   dense rows (token-major, or the flat re-view of a cache block): 16-byte loads along the row.
 template <typename T>
-__device__ float block_score_wave(const T* __restrict__ base, int layout, int num_kv_heads,
-                                  int head_size, int block_size, float* norms /* LDS [bs*H] */,
-                                  float* means /* LDS [bs] */) {
-  const int lane = threadIdx.x & 63;
+__device__ void block_pair_norms(const T* __restrict__ base, int layout, int num_kv_heads,
+                                 int head_size, int block_size, float* norms, char* stage_raw) {
+  const int tid = threadIdx.x;
+  const int nthr = blockDim.x;
   const int pairs = block_size * num_kv_heads;
-  for (int p = lane; p < pairs; p += 64) {
-    // pair p = (row t, head h) of the [block_size, H, D] view
-    const int t = p / num_kv_heads, h = p % num_kv_heads;
-    float ss = 0.f;
-    if (layout == PE_SCORE_CACHE) {
-      const T* v = base + (int64_t)h * head_size * block_size + t;  // V[h][d][t]
+  constexpr int X = 16 / sizeof(T);
+  if (layout == PE_SCORE_CACHE) {
+    const int slab = head_size * block_size;  // elements of one head
+    const int g = score_heads_per_pass(num_kv_heads, head_size, block_size, (int)sizeof(T));
+    const bool vec_ok = g > 0 && slab % X == 0 && block_size % X == 0 && ((uintptr_t)base % 16) == 0;
+    if (vec_ok) {
+      T* stage = reinterpret_cast<T*>(stage_raw);
+      const int lds_slab = slab + block_size;
+      const int chunks_per_head = slab / X;
+      for (int h0 = 0; h0 < num_kv_heads; h0 += g) {
+        const int nh = min(g, num_kv_heads - h0);
+        for (int c = tid; c < nh * chunks_per_head; c += nthr) {
+          const int hh = c / chunks_per_head, w = c % chunks_per_head;
+          *reinterpret_cast<u32x4*>(stage + hh * lds_slab + w * X) =
+              *reinterpret_cast<const u32x4*>(base + (int64_t)(h0 + hh) * slab + w * X);
+        }
+        __syncthreads();
+        for (int p = tid; p < nh * block_size; p += nthr) {
+          const int hh = p / block_size, t = p % block_size;
+          const T* v = stage + hh * lds_slab + t;
+          float ss = 0.f;
+          for (int d = 0; d < head_size; ++d) {
+            const float x = to_f32(v[d * block_size]);
+            ss += x * x;
+          }
+          norms[t * num_kv_heads + h0 + hh] = round_to<T>(sqrtf(ss));
+        }
+        __syncthreads();
+      }
+      return;
+    }
+    for (int p = tid; p < pairs; p += nthr) {
+      const int t = p / num_kv_heads, h = p % num_kv_heads;
+      const T* v = base + (int64_t)h * slab + t;  // V[h][d][t]
+      float ss = 0.f;
       for (int d = 0; d < head_size; ++d) {
         const float x = to_f32(v[(int64_t)d * block_size]);
         ss += x * x;
       }
-    } else {
-      const T* v = base + (int64_t)p * head_size;  // dense rows (token-major or flat re-view)
-      constexpr int X = 16 / sizeof(T);
-      if (head_size % X == 0 && ((uintptr_t)v % 16) == 0) {
-        // 16-byte loads, elements still accumulated in ascending order
-        for (int d = 0; d < head_size; d += X) {
-          union {
-            u32x4 raw;
-            T e[X];
-          } u;
-          u.raw = *reinterpret_cast<const u32x4*>(v + d);
+      norms[p] = round_to<T>(sqrtf(ss));
+    }
+    __syncthreads();
+    return;
+  }
+  for (int p = tid; p < pairs; p += nthr) {
+    const T* v = base + (int64_t)p * head_size;  // dense rows (token-major or flat re-view)
+    float ss = 0.f;
+    if (head_size % X == 0 && ((uintptr_t)v % 16) == 0) {
+      // 16-byte loads, elements still accumulated in ascending order
+      for (int d = 0; d < head_size; d += X) {
+        union {
+          u32x4 raw;
+          T e[X];
+        } u;
+        u.raw = *reinterpret_cast<const u32x4*>(v + d);
 #pragma unroll
-          for (int e = 0; e < X; ++e) {
-            const float x = to_f32(u.e[e]);
-            ss += x * x;
-          }
-        }
-      } else {
-        for (int d = 0; d < head_size; ++d) {
-          const float x = to_f32(v[d]);
+        for (int e = 0; e < X; ++e) {
+          const float x = to_f32(u.e[e]);
           ss += x * x;
         }
+      }
+    } else {
+      for (int d = 0; d < head_size; ++d) {
+        const float x = to_f32(v[d]);
+        ss += x * x;
       }
     }
     norms[p] = round_to<T>(sqrtf(ss));
   }
   __syncthreads();
-  for (int t = lane; t < block_size; t += 64) {
+}
+
+// Score of one block (every thread of the workgroup returns it).  Follows torch's evaluation of
+//   norm(V, dim=-1).mean(dim=1).sum(dim=0)
+// on a low-precision tensor: every reduction accumulates in f32 and its result is rounded to
+// the storage type.
+template <typename T>
+__device__ float block_score_wg(const T* __restrict__ base, int layout, int num_kv_heads,
+                                int head_size, int block_size, float* norms /* LDS [bs*H] */,
+                                float* means /* LDS [bs] */, char* stage) {
+  block_pair_norms<T>(base, layout, num_kv_heads, head_size, block_size, norms, stage);
+  for (int t = threadIdx.x; t < block_size; t += blockDim.x) {
     float hs = 0.f;
     for (int h = 0; h < num_kv_heads; ++h) hs += norms[t * num_kv_heads + h];
     means[t] = round_to<T>(hs / (float)num_kv_heads);
@@ -68,74 +141,43 @@ __device__ float block_score_wave(const T* __restrict__ base, int layout, int nu
   __syncthreads();
   float total = 0.f;
   for (int t = 0; t < block_size; ++t) total += means[t];
+  __syncthreads();  // norms/means may be reused by the caller's next block
   return round_to<T>(total);
 }
 
+__device__ inline char* score_stage_ptr(float* norms, int num_kv_heads, int block_size) {
+  size_t n = (size_t)(block_size * num_kv_heads + block_size) * 4;
+  n = (n + 15) & ~(size_t)15;
+  return reinterpret_cast<char*>(norms) + n;
+}
+
 template <typename T>
-__global__ __launch_bounds__(64) void block_score_kernel(float* __restrict__ scores,
-                                                         const T* __restrict__ values,
-                                                         const int32_t* __restrict__ block_ids,
-                                                         int layout, int64_t block_stride,
-                                                         int num_kv_heads, int head_size,
-                                                         int block_size) {
+__global__ __launch_bounds__(SCORE_THREADS) void block_score_kernel(
+    float* __restrict__ scores, const T* __restrict__ values, const int32_t* __restrict__ block_ids,
+    int layout, int64_t block_stride, int num_kv_heads, int head_size, int block_size) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* norms = reinterpret_cast<float*>(smem);
   float* means = norms + block_size * num_kv_heads;
   const int i = blockIdx.x;
   const int64_t blk = block_ids ? block_ids[i] : i;
-  const float s = block_score_wave<T>(values + blk * block_stride, layout, num_kv_heads, head_size,
-                                      block_size, norms, means);
+  const float s = block_score_wg<T>(values + blk * block_stride, layout, num_kv_heads, head_size,
+                                    block_size, norms, means,
+                                    score_stage_ptr(norms, num_kv_heads, block_size));
   if (threadIdx.x == 0) scores[i] = s;
 }
 
 // Head-sharded scoring, step 1: per token, the sum over this rank's heads of the rounded norms.
 template <typename T>
-__global__ __launch_bounds__(64) void block_token_norm_sums_kernel(
+__global__ __launch_bounds__(SCORE_THREADS) void block_token_norm_sums_kernel(
     float* __restrict__ sums, const T* __restrict__ values, const int32_t* __restrict__ block_ids,
     int layout, int64_t block_stride, int num_kv_heads, int head_size, int block_size) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* norms = reinterpret_cast<float*>(smem);
-  const int lane = threadIdx.x;
   const int i = blockIdx.x;
   const int64_t blk = block_ids ? block_ids[i] : i;
-  const T* base = values + blk * block_stride;
-  const int pairs = block_size * num_kv_heads;
-  for (int p = lane; p < pairs; p += 64) {
-    const int t = p / num_kv_heads, h = p % num_kv_heads;
-    float ss = 0.f;
-    if (layout == PE_SCORE_CACHE) {
-      const T* v = base + (int64_t)h * head_size * block_size + t;
-      for (int d = 0; d < head_size; ++d) {
-        const float x = to_f32(v[(int64_t)d * block_size]);
-        ss += x * x;
-      }
-    } else {
-      const T* v = base + (int64_t)p * head_size;
-      constexpr int X = 16 / sizeof(T);
-      if (head_size % X == 0 && ((uintptr_t)v % 16) == 0) {
-        for (int d = 0; d < head_size; d += X) {
-          union {
-            u32x4 raw;
-            T e[X];
-          } u;
-          u.raw = *reinterpret_cast<const u32x4*>(v + d);
-#pragma unroll
-          for (int e = 0; e < X; ++e) {
-            const float x = to_f32(u.e[e]);
-            ss += x * x;
-          }
-        }
-      } else {
-        for (int d = 0; d < head_size; ++d) {
-          const float x = to_f32(v[d]);
-          ss += x * x;
-        }
-      }
-    }
-    norms[p] = round_to<T>(sqrtf(ss));
-  }
-  __syncthreads();
-  for (int t = lane; t < block_size; t += 64) {
+  block_pair_norms<T>(values + blk * block_stride, layout, num_kv_heads, head_size, block_size,
+                      norms, score_stage_ptr(norms, num_kv_heads, block_size));
+  for (int t = threadIdx.x; t < block_size; t += blockDim.x) {
     float hs = 0.f;
     for (int h = 0; h < num_kv_heads; ++h) hs += norms[t * num_kv_heads + h];
     sums[(int64_t)i * block_size + t] = hs;
@@ -156,10 +198,13 @@ __global__ __launch_bounds__(64) void block_score_from_sums_kernel(float* __rest
   scores[i] = round_to<T>(total);
 }
 
-// One wave per sequence (grid = batch), or a single wave walking all rows serially when the
-// reference's in-loop slice has to be reproduced (compat_q1).
+// One workgroup per sequence (grid = batch), or a single workgroup walking all rows serially
+// when the reference's in-loop slice has to be reproduced (compat_q1).  All waves score the
+// just-filled block together and copy the table; the selection over the score list is
+// computed redundantly by every wave (same inputs, same result, so control flow stays uniform)
+// and written by wave 0.
 template <typename T>
-__global__ __launch_bounds__(64) void evict_select_compact_kernel(
+__global__ __launch_bounds__(SCORE_THREADS) void evict_select_compact_kernel(
     int32_t* __restrict__ rmv_idx_out, int32_t* __restrict__ out_tables,
     int64_t* __restrict__ zero_slots_out, const int32_t* __restrict__ block_tables,
     const int32_t* __restrict__ seq_lens, const int32_t* __restrict__ num_blocks,
@@ -172,7 +217,9 @@ __global__ __launch_bounds__(64) void evict_select_compact_kernel(
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* norms = reinterpret_cast<float*>(smem);
   float* means = norms + block_size * num_kv_heads;
-  const int lane = threadIdx.x;
+  char* stage = score_stage_ptr(norms, num_kv_heads, block_size);
+  const int lane = threadIdx.x & 63;
+  const bool writer = threadIdx.x < 64;  // wave 0
   const int b_begin = compat_q1 ? 0 : blockIdx.x;
   const int b_end = compat_q1 ? batch : blockIdx.x + 1;
   const int w = out_width;
@@ -202,16 +249,18 @@ __global__ __launch_bounds__(64) void evict_select_compact_kernel(
             s = new_scores[b];  // scored by the caller (head-sharded caches)
           } else {
             const int last_blk = row[num_blocks[b] - 1];
-            s = block_score_wave<T>(value_cache + (int64_t)last_blk * kv_block_stride, score_layout,
-                                    num_kv_heads, head_size, block_size, norms, means);
+            s = block_score_wg<T>(value_cache + (int64_t)last_blk * kv_block_stride, score_layout,
+                                  num_kv_heads, head_size, block_size, norms, means, stage);
           }
           // the appended entry is kept in a register (every lane holds s): entries written
           // in this launch are never read back through memory
           int n_new = -1;
           if (n < score_table_width) {
-            if (lane == 0) list[n] = s;
+            if (threadIdx.x == 0) list[n] = s;
             n_new = n;
             n += 1;
+          } else if (threadIdx.x == 0) {
+            atomicOr(&evict_diag_word, (unsigned)PE_DIAG_SCORE_ROW_FULL);
           }
           int start = 1, end = (method == PE_EVICT_LOCAL) ? 1 + topk_blocks : n - 1;
           if (end > n) end = n;
@@ -249,32 +298,32 @@ __global__ __launch_bounds__(64) void evict_select_compact_kernel(
               float v = 0.f;
               if (i < n - 1) v = (i + 1 == n_new) ? s : list[i + 1];
               __syncthreads();
-              if (i < n - 1) list[i] = v;
+              if (writer && i < n - 1) list[i] = v;
               __syncthreads();
             }
             n -= 1;
           }
-          if (lane == 0) score_counts[srow] = n;
+          if (threadIdx.x == 0) score_counts[srow] = n;
         } else {
           rmv = ov;  // host-chosen victim (random mode) without score bookkeeping
         }
       }
     }
-    if (lane == 0) {
+    if (threadIdx.x == 0) {
       rmv_idx_out[b] = rmv;
       if (zero_slots_out) zero_slots_out[b] = zslot;
     }
     if (out_tables != nullptr && w > 0) {
       int32_t* o = out_tables + (int64_t)b * w;
       if (!compat_q1 || b == 0) {
-        for (int j = lane; j < w; j += 64) {
+        for (int j = threadIdx.x; j < w; j += blockDim.x) {
           const int src = (rmv >= 0 && j >= rmv) ? j + 1 : j;
           o[j] = src < max_blocks ? row[src] : 0;
         }
       } else {
         // rows after the first see a table already cut to width w by the reference's slice
         // inside its loop: removing a column leaves w-1 new entries and the old last one stays
-        for (int j = lane; j < w; j += 64) {
+        for (int j = threadIdx.x; j < w; j += blockDim.x) {
           int32_t v;
           if (rmv >= 0 && rmv < w) {
             v = (j < rmv) ? row[j] : (j < w - 1 ? row[j + 1] : row[w - 1]);
@@ -286,6 +335,16 @@ __global__ __launch_bounds__(64) void evict_select_compact_kernel(
       }
     }
   }
+}
+
+// this file's diagnostic word (see pe_device_diagnostics)
+int evict_diag_fetch(unsigned int* out, int reset) {
+  void* p = nullptr;
+  hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(evict_diag_word));
+  if (e == hipSuccess) e = hipMemcpy(out, p, sizeof(unsigned int), hipMemcpyDeviceToHost);
+  if (e == hipSuccess && reset && *out != 0) e = hipMemset(p, 0, sizeof(unsigned int));
+  if (e != hipSuccess) return fail(PE_ERR_LAUNCH, "evict diagnostics: %s", hipGetErrorString(e));
+  return PE_OK;
 }
 
 }  // namespace pe
@@ -304,9 +363,10 @@ int pe_block_score_value_l2(float* scores_out, const void* values, const int32_t
              "block_score: bad sizes");
   PE_REQUIRE(block_size * num_kv_heads <= SCORE_MAX_PAIRS, PE_ERR_UNSUPPORTED,
              "block_size*num_kv_heads too large for the score kernel");
-  const size_t lds = (size_t)(block_size * num_kv_heads + block_size) * 4;
+  const size_t lds = score_lds_bytes(layout, num_kv_heads, head_size, block_size, elem_size(dtype));
   PE_DISPATCH_ALL(dtype, T,
-                  hipLaunchKernelGGL(block_score_kernel<T>, dim3((unsigned)n_blocks), dim3(64), lds,
+                  hipLaunchKernelGGL(block_score_kernel<T>, dim3((unsigned)n_blocks),
+                                     dim3(SCORE_THREADS), lds,
                                      static_cast<hipStream_t>(stream), scores_out, (const T*)values,
                                      block_ids, layout, block_stride, num_kv_heads, head_size,
                                      block_size));
@@ -326,10 +386,10 @@ int pe_block_token_norm_sums(float* sums_out, const void* values, const int32_t*
              "block_token_norm_sums: bad sizes");
   PE_REQUIRE(block_size * num_kv_heads <= SCORE_MAX_PAIRS, PE_ERR_UNSUPPORTED,
              "block_size*num_kv_heads too large for the score kernel");
-  const size_t lds = (size_t)(block_size * num_kv_heads) * 4;
+  const size_t lds = score_lds_bytes(layout, num_kv_heads, head_size, block_size, elem_size(dtype));
   PE_DISPATCH_ALL(dtype, T,
                   hipLaunchKernelGGL(block_token_norm_sums_kernel<T>, dim3((unsigned)n_blocks),
-                                     dim3(64), lds, static_cast<hipStream_t>(stream), sums_out,
+                                     dim3(SCORE_THREADS), lds, static_cast<hipStream_t>(stream), sums_out,
                                      (const T*)values, block_ids, layout, block_stride, num_kv_heads,
                                      head_size, block_size));
   return check_launch("block_token_norm_sums");
@@ -390,13 +450,13 @@ int pe_evict_select_compact(int32_t* rmv_idx_out, int32_t* out_tables, int64_t* 
                    PE_ERR_INVALID_ARG, "bad head layout for block scoring");
         PE_REQUIRE(score_layout == PE_SCORE_CACHE || score_layout == PE_SCORE_CACHE_FLAT,
                    PE_ERR_INVALID_ARG, "decode-time scores read the paged cache (layout 1 or 2)");
-        lds = (size_t)(block_size * num_kv_heads + block_size) * 4;
+        lds = score_lds_bytes(score_layout, num_kv_heads, head_size, block_size, elem_size(dtype));
       }
     }
   }
   const unsigned grid = compat_q1 ? 1u : (unsigned)batch;
   PE_DISPATCH_ALL(dtype, T,
-                  hipLaunchKernelGGL(evict_select_compact_kernel<T>, dim3(grid), dim3(64), lds,
+                  hipLaunchKernelGGL(evict_select_compact_kernel<T>, dim3(grid), dim3(SCORE_THREADS), lds,
                                      static_cast<hipStream_t>(stream), rmv_idx_out, out_tables,
                                      zero_slots_out, block_tables, seq_lens, num_blocks,
                                      victim_override, batch, max_blocks, out_width, method, cache_budget,

@@ -49,6 +49,10 @@ constexpr int DEC_WAVES = PE_DEC_WAVES;
 constexpr int DEC_THREADS = DEC_WAVES * 64;
 constexpr float NEG_BIG = -1.0e30f;
 
+// Set when a sequence length exceeds what its block-table row addresses and the kernel clamps
+// it (a caller bug the launch itself survives); read back through pe_device_diagnostics.
+static __device__ unsigned int decode_diag_word;
+
 template <typename T, int HEAD_SIZE>
 struct DecTile {
   typename Traits<T>::vec8 k[2][HEAD_SIZE / 32];
@@ -96,8 +100,12 @@ __global__ __launch_bounds__(DEC_THREADS, (HEAD_SIZE <= 128 ? PE_DEC_OCC : 2)) v
   int tbl_base = 0;
   int tbl_reg = lane < max_num_blocks_per_seq ? table[lane] : 0;
 
-  // a length beyond what the table row can address is clamped (never read past the row)
-  const int seq_len = min(seq_lens[seq], max_num_blocks_per_seq * BS);
+  // a length beyond what the table row can address is clamped (never read past the row) and
+  // reported through the diagnostic word
+  const int raw_len = seq_lens[seq];
+  const int seq_len = min(raw_len, max_num_blocks_per_seq * BS);
+  if (raw_len > max_num_blocks_per_seq * BS && threadIdx.x == 0 && split == 0 && kvh == 0)
+    atomicOr(&decode_diag_word, (unsigned)PE_DIAG_DECODE_LEN_CLAMPED);
   // Fused KV write: the step's new token (position seq_len-1) is taken from new_key/new_value
   // directly and only the seq_len-1 older tokens are read from the cache, so the store of the
   // new row into the cache needs no ordering against this kernel's loads.
@@ -371,8 +379,12 @@ __global__ __launch_bounds__(256) void paged_decode_generic_kernel(
   float* logits = red + 8;                            // [seq_len]
   const int head = blockIdx.x, seq = blockIdx.y;
   const int kvh = head / (num_heads / num_kv_heads);
-  // clamped to what the table row addresses and to the LDS logits buffer
-  const int seq_len = min(seq_lens[seq], min(max_num_blocks_per_seq * block_size, max_len));
+  // clamped to what the table row addresses and to the LDS logits buffer (reported through the
+  // diagnostic word)
+  const int raw_len = seq_lens[seq];
+  const int seq_len = min(raw_len, min(max_num_blocks_per_seq * block_size, max_len));
+  if (raw_len > seq_len && threadIdx.x == 0 && head == 0)
+    atomicOr(&decode_diag_word, (unsigned)PE_DIAG_DECODE_LEN_CLAMPED);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int32_t* table = block_tables + (int64_t)seq * max_num_blocks_per_seq;
   const float slope = alibi_slopes ? alibi_slopes[head] : 0.f;
@@ -483,6 +495,15 @@ static bool mfma_path_ok(int num_heads, int num_kv_heads, int head_size, int blo
   if (num_heads / num_kv_heads > 16) return false;
   if (q_stride % 8 || kv_block_stride % 8 || kv_head_stride % 8) return false;
   return true;
+}
+
+int decode_diag_fetch(unsigned int* out, int reset) {
+  void* p = nullptr;
+  hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(decode_diag_word));
+  if (e == hipSuccess) e = hipMemcpy(out, p, sizeof(unsigned int), hipMemcpyDeviceToHost);
+  if (e == hipSuccess && reset && *out != 0) e = hipMemset(p, 0, sizeof(unsigned int));
+  if (e != hipSuccess) return fail(PE_ERR_LAUNCH, "decode diagnostics: %s", hipGetErrorString(e));
+  return PE_OK;
 }
 
 }  // namespace pe

@@ -80,6 +80,33 @@ def _check_kv_cache_args(kv_cache_dtype: str, k_scale: float, v_scale: float) ->
         raise RuntimeError("paged_evict: k_scale and v_scale must be 1.0")
 
 
+DIAG_DECODE_LEN_CLAMPED, DIAG_SCORE_ROW_FULL = 1, 2
+
+
+def device_diagnostics(reset: bool = True) -> int:
+    """Flags the kernels set on the current device when they had to clamp inconsistent arguments
+    (PE_DIAG_* of include/paged_evict.h).  Synchronises the device: for tests and debugging."""
+    import ctypes
+    flags = ctypes.c_uint(0)
+    lib = _lib.load()
+    _lib.check(lib.pe_device_diagnostics(ctypes.addressof(flags), 1 if reset else 0),
+               "device_diagnostics")
+    return int(flags.value)
+
+
+def check_device_diagnostics() -> None:
+    """Raise if any kernel since the last check clamped a sequence length to its block table or
+    dropped a block score because the score row was full."""
+    flags = device_diagnostics(reset=True)
+    if flags:
+        what = []
+        if flags & DIAG_DECODE_LEN_CLAMPED:
+            what.append("a decode launch got a seq_lens entry beyond its block-table row")
+        if flags & DIAG_SCORE_ROW_FULL:
+            what.append("a block score was dropped because the sequence's score row was full")
+        raise RuntimeError("paged_evict device diagnostics: " + "; ".join(what))
+
+
 # --------------------------------------------------------------------------------------
 def reshape_and_cache(key: torch.Tensor, value: torch.Tensor, key_cache: torch.Tensor,
                       value_cache: torch.Tensor, slot_mapping: torch.Tensor,
@@ -293,6 +320,11 @@ def swap_blocks(src: torch.Tensor, dst: torch.Tensor, block_mapping: torch.Tenso
 
 
 # --------------------------------------------------------------------------------------
+# measurement hook: when set to a list, prefill_causal brackets its launch with events on the
+# launch stream and appends (start, end)
+prefill_event_sink = None
+
+
 def prefill_causal(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor,
                    cu_q: torch.Tensor, cu_kv: torch.Tensor, max_q_len: int, scale: float,
                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -315,10 +347,17 @@ def prefill_causal(query: torch.Tensor, key: torch.Tensor, value: torch.Tensor,
     if out is None:
         out = torch.empty((Tq, Hq, D), dtype=query.dtype, device=dev)
     lib = _lib.load()
+    sink = prefill_event_sink
+    if sink is not None:
+        s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s_ev.record()
     _lib.check(lib.pe_prefill_causal(
         _p(out), _p(query), _p(key), _p(value), _p(cu_q), _p(cu_kv), cu_q.numel() - 1,
         int(max_q_len), Hq, Hkv, D, query.stride(0), key.stride(0), value.stride(0),
         out.stride(0), float(scale), _dtype_code(query), _stream(dev)), "prefill_causal")
+    if sink is not None:
+        e_ev.record()
+        sink.append((s_ev, e_ev))
     return out
 
 
@@ -602,6 +641,8 @@ class DecodeLayerLauncher:
         if query.dtype != kv_cache.dtype or key.dtype != kv_cache.dtype or value.dtype != kv_cache.dtype:
             raise RuntimeError("decode launcher: dtype mismatch")
         self.v_off = kv_cache.stride(0) * es
+        self._out_numel = S * num_heads * head_size
+        self._out_dtype = kv_cache.dtype
         dt = _dtype_code(query)
         stream = _stream(dev)
         nz = 0 if zero_slots is None else zero_slots.numel()
@@ -645,6 +686,10 @@ class DecodeLayerLauncher:
     event_sink = None
 
     def run(self, query, key, value, kv_cache, out) -> None:
+        # the kernels write a dense [S, Hq, D] tensor of the cache dtype at out's address
+        if out.numel() != self._out_numel or out.dtype != self._out_dtype or not out.is_contiguous():
+            raise RuntimeError("decode launcher: output must be a contiguous tensor of "
+                               f"{self._out_numel} {self._out_dtype} elements")
         kc = kv_cache.data_ptr()
         vc = kc + self.v_off
         lib = self._lib

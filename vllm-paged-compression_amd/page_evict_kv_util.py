@@ -43,7 +43,9 @@ def get_num_required_blocks_after_prune_promt(q_len: int, paged_evict_config,
     head = cfg.initial_blocks * block_size
     end_middle = q_len - block_size - q_len % block_size
     middle_kept = max(cfg.cache_budget - head - block_size, 0)
-    total = head + middle_kept + (q_len - end_middle)
+    # never more than the prompt holds (a budget that is not a whole number of blocks, which
+    # PagedEvictConfig rounds away, would otherwise overshoot for prompts just above it)
+    total = min(q_len, head + middle_kept + (q_len - end_middle))
     return cdiv(total, block_size), total
 
 

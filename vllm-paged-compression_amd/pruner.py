@@ -51,6 +51,11 @@ class KVCachePruner:
         assert cache_prune_type == "budget"
         assert cache_budget >= 3 * block_size, \
             "Cache budget must be at least 3 times the original block size"
+        if cache_budget % block_size != 0:
+            # floor(L/bs)*bs < budget < L would make get_pruned_length exceed L: the kept-row
+            # index would then address rows past the prompt
+            raise ValueError(f"cache_budget {cache_budget} must be a multiple of the block size "
+                             f"{block_size}")
         if evict_method not in _STREAMING + _TOKEN_LEVEL:
             raise ValueError(f"Unknown eviction method: {evict_method}")
 
@@ -66,7 +71,7 @@ class KVCachePruner:
             return seq_len
         bs = self.orig_block_size
         end_middle = seq_len - bs - seq_len % bs
-        return bs + max(self.cache_budget - 2 * bs, 0) + (seq_len - end_middle)
+        return min(seq_len, bs + max(self.cache_budget - 2 * bs, 0) + (seq_len - end_middle))
 
     def prunes(self, seq_len: int) -> bool:
         """Whether a prompt of this length loses tokens."""
