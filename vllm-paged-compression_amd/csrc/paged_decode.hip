@@ -32,7 +32,7 @@ namespace pe {
 
 // Build-time tunables of the MFMA path (the defaults are the measured optimum on MI355X)
 #ifndef PE_DEC_WAVES
-#define PE_DEC_WAVES 4  // waves per workgroup
+#define PE_DEC_WAVES 4  // waves per workgroup of the default (throughput) shape
 #endif
 #ifndef PE_DEC_TILES
 #define PE_DEC_TILES 2  // 32-token tiles in flight per wave (head sizes up to 128)
@@ -47,6 +47,7 @@ namespace pe {
 #endif
 constexpr int DEC_WAVES = PE_DEC_WAVES;
 constexpr int DEC_THREADS = DEC_WAVES * 64;
+constexpr int DEC_MAX_WAVES = 16;  // widest workgroup (one per CU, four waves per SIMD)
 constexpr float NEG_BIG = -1.0e30f;
 
 // Set when a sequence length exceeds what its block-table row addresses and the kernel clamps
@@ -62,8 +63,14 @@ struct DecTile {
 // Partial results of one split: [split][seq][head] -> m, l, then O[D] (all f32)
 __host__ __device__ inline int64_t ws_stride(int head_size) { return head_size + 2; }
 
-template <typename T, int HEAD_SIZE>
-__global__ __launch_bounds__(DEC_THREADS, (HEAD_SIZE <= 128 ? PE_DEC_OCC : 2)) void paged_decode_mfma_kernel(
+// WAVES: waves per workgroup.  4 (two workgroups per CU) is the throughput shape; 8 and 16 are
+// the latency shapes for launches with few (sequence, KV head) pairs: the block pairs of a
+// sequence spread over more waves of ONE workgroup, which merges them through LDS, instead of
+// over KV splits that need a second launch to be merged.  16 waves leave 128 registers per
+// wave, enough for one tile in flight.
+template <typename T, int HEAD_SIZE, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, (WAVES >= 16 ? 4 : (HEAD_SIZE <= 128 ? PE_DEC_OCC : 2)))
+void paged_decode_mfma_kernel(
     T* __restrict__ out, float* __restrict__ ws, const T* __restrict__ query,
     const T* __restrict__ key_cache, const T* __restrict__ value_cache,
     const int32_t* __restrict__ block_tables, const int32_t* __restrict__ seq_lens,
@@ -239,7 +246,7 @@ __global__ __launch_bounds__(DEC_THREADS, (HEAD_SIZE <= 128 ? PE_DEC_OCC : 2)) v
   };
 
   // ---- main loop: waves interleave over the split's block pairs ----------------------
-  if constexpr (HEAD_SIZE <= 128 && PE_DEC_TILES == 2) {
+  if constexpr (HEAD_SIZE <= 128 && PE_DEC_TILES == 2 && WAVES < 16) {
     // two tiles in flight per wave (the next pair's 16 KB is requested before the current
     // pair is consumed)
     DecTile<T, HEAD_SIZE> t0, t1;
@@ -247,20 +254,20 @@ __global__ __launch_bounds__(DEC_THREADS, (HEAD_SIZE <= 128 ? PE_DEC_OCC : 2)) v
     if (p < pair_end) {
       issue(t0, p);
       while (true) {
-        if (p + DEC_WAVES < pair_end) issue(t1, p + DEC_WAVES);
+        if (p + WAVES < pair_end) issue(t1, p + WAVES);
         compute(t0, 2 * p * BS, cached_len);
-        p += DEC_WAVES;
+        p += WAVES;
         if (p >= pair_end) break;
-        if (p + DEC_WAVES < pair_end) issue(t0, p + DEC_WAVES);
+        if (p + WAVES < pair_end) issue(t0, p + WAVES);
         compute(t1, 2 * p * BS, cached_len);
-        p += DEC_WAVES;
+        p += WAVES;
         if (p >= pair_end) break;
       }
     }
   } else {
     // head_size 256: one tile per wave fits the register file; occupancy hides latency
     DecTile<T, HEAD_SIZE> t0;
-    for (int p = pair_begin + wave; p < pair_end; p += DEC_WAVES) {
+    for (int p = pair_begin + wave; p < pair_end; p += WAVES) {
       issue(t0, p);
       compute(t0, 2 * p * BS, cached_len);
     }
@@ -268,7 +275,7 @@ __global__ __launch_bounds__(DEC_THREADS, (HEAD_SIZE <= 128 ? PE_DEC_OCC : 2)) v
 
   // ---- the step's new token: attention contribution from registers + store into the cache --
   if (has_new && split == 0 &&
-      wave == ((pair_end > pair_begin ? pair_end - pair_begin : 0) % DEC_WAVES)) {
+      wave == ((pair_end > pair_begin ? pair_end - pair_begin : 0) % WAVES)) {
     const T* ksrc = new_key + (int64_t)seq * new_k_stride + (int64_t)kvh * HEAD_SIZE;
     const T* vsrc = new_value + (int64_t)seq * new_v_stride + (int64_t)kvh * HEAD_SIZE;
     DecTile<T, HEAD_SIZE> tn;
@@ -302,30 +309,33 @@ __global__ __launch_bounds__(DEC_THREADS, (HEAD_SIZE <= 128 ? PE_DEC_OCC : 2)) v
   l_run += __shfl_xor(l_run, 16);
   l_run += __shfl_xor(l_run, 32);
 
-  __shared__ float sm_o[DEC_WAVES][16][HEAD_SIZE + 4];
-  __shared__ float sm_m[DEC_WAVES][16];
-  __shared__ float sm_l[DEC_WAVES][16];
+  // dynamic LDS: o[WAVES][gqa][HEAD_SIZE + 4], m[WAVES][16], l[WAVES][16] (f32)
+  extern __shared__ __attribute__((aligned(16))) float dec_smem[];
+  constexpr int OROW = HEAD_SIZE + 4;
+  float* sm_o = dec_smem;
+  float* sm_m = dec_smem + WAVES * gqa * OROW;
+  float* sm_l = sm_m + WAVES * 16;
   if (hc < gqa) {
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
-      *reinterpret_cast<f32x4*>(&sm_o[wave][hc][16 * dt + 4 * g]) = acc[dt];
+      *reinterpret_cast<f32x4*>(&sm_o[(wave * gqa + hc) * OROW + 16 * dt + 4 * g]) = acc[dt];
     if (g == 0) {
-      sm_m[wave][hc] = m_run;
-      sm_l[wave][hc] = l_run;
+      sm_m[wave * 16 + hc] = m_run;
+      sm_l[wave * 16 + hc] = l_run;
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < gqa * HEAD_SIZE; i += DEC_THREADS) {
+  for (int i = threadIdx.x; i < gqa * HEAD_SIZE; i += WAVES * 64) {
     const int h = i / HEAD_SIZE, d = i % HEAD_SIZE;
-    float m_tot = sm_m[0][h];
+    float m_tot = sm_m[h];
 #pragma unroll
-    for (int w = 1; w < DEC_WAVES; ++w) m_tot = fmaxf(m_tot, sm_m[w][h]);
+    for (int w = 1; w < WAVES; ++w) m_tot = fmaxf(m_tot, sm_m[w * 16 + h]);
     float o = 0.f, l = 0.f;
 #pragma unroll
-    for (int w = 0; w < DEC_WAVES; ++w) {
-      const float f = __expf(sm_m[w][h] - m_tot);
-      o += f * sm_o[w][h][d];
-      l += f * sm_l[w][h];
+    for (int w = 0; w < WAVES; ++w) {
+      const float f = __expf(sm_m[w * 16 + h] - m_tot);
+      o += f * sm_o[(w * gqa + h) * OROW + d];
+      l += f * sm_l[w * 16 + h];
     }
     const int head = kvh * gqa + h;
     if (num_splits == 1) {
@@ -341,24 +351,36 @@ __global__ __launch_bounds__(DEC_THREADS, (HEAD_SIZE <= 128 ? PE_DEC_OCC : 2)) v
   }
 }
 
-// merge of the split partials: grid (num_heads, num_seqs), one thread per d
-template <typename T>
+// merge of the split partials: grid (num_heads, num_seqs), one thread per d.  All partials of
+// a thread are requested before any is used (one memory round trip instead of one per pass).
+template <typename T, int MAX_SPLITS>
 __global__ void paged_decode_merge_kernel(T* __restrict__ out, const float* __restrict__ ws,
                                           int num_heads, int head_size, int num_splits) {
   const int head = blockIdx.x, seq = blockIdx.y, num_seqs = gridDim.y;
   const int64_t stride = ws_stride(head_size);
-  float m_tot = NEG_BIG;
-  for (int s = 0; s < num_splits; ++s)
-    m_tot = fmaxf(m_tot, ws[(((int64_t)s * num_seqs + seq) * num_heads + head) * stride]);
+  const int64_t split_stride = (int64_t)num_seqs * num_heads * stride;
+  const float* base = ws + ((int64_t)seq * num_heads + head) * stride;
   for (int d = threadIdx.x; d < head_size; d += blockDim.x) {
-    float o = 0.f, l = 0.f;
-    for (int s = 0; s < num_splits; ++s) {
-      const float* w = ws + (((int64_t)s * num_seqs + seq) * num_heads + head) * stride;
-      const float f = __expf(w[0] - m_tot);
-      o += f * w[2 + d];
-      l += f * w[1];
+    float m[MAX_SPLITS], l[MAX_SPLITS], o[MAX_SPLITS];
+#pragma unroll
+    for (int s = 0; s < MAX_SPLITS; ++s) {
+      const bool on = s < num_splits;
+      const float* w = base + (on ? s : 0) * split_stride;
+      m[s] = on ? w[0] : NEG_BIG;
+      l[s] = on ? w[1] : 0.f;
+      o[s] = on ? w[2 + d] : 0.f;
     }
-    out[((int64_t)seq * num_heads + head) * head_size + d] = (T)(o * (1.f / (l + 1e-6f)));
+    float m_tot = NEG_BIG;
+#pragma unroll
+    for (int s = 0; s < MAX_SPLITS; ++s) m_tot = fmaxf(m_tot, m[s]);
+    float acc = 0.f, lsum = 0.f;
+#pragma unroll
+    for (int s = 0; s < MAX_SPLITS; ++s) {
+      const float f = __expf(m[s] - m_tot);
+      acc += f * o[s];
+      lsum += f * l[s];
+    }
+    out[((int64_t)seq * num_heads + head) * head_size + d] = (T)(acc * (1.f / (lsum + 1e-6f)));
   }
 }
 
@@ -444,33 +466,24 @@ static int env_int(const char* name, int dflt) {
   return v ? atoi(v) : dflt;
 }
 
-// Upper limit of the split count for a maximum length: every wave of a split must have at least
-// two block pairs.  pe_paged_decode_workspace_bytes sizes the workspace with it and choose_splits
-// never exceeds it, whatever the tunables say.
+// Upper limit of the split count for a maximum length: a split has at least one block pair per
+// wave of the narrowest workgroup.  pe_paged_decode_workspace_bytes sizes the workspace with it
+// and choose_shape never exceeds it, whatever the tunables say.
 static int split_cap(int max_seq_len) {
   const int n_pairs = (max_seq_len + 31) / 32;
-  int cap = n_pairs / (2 * DEC_WAVES);
+  int cap = n_pairs / DEC_WAVES;
   if (cap < 1) cap = 1;
   if (cap > 64) cap = 64;
   return cap;
 }
 
-// Number of KV splits.  A split costs a second (merge) launch and a round trip of the partial
-// results, about 3 us, so it only pays when the workgroups are few AND long.  Measured on MI355X
-// (4 query heads per KV head, head 128): with at most 64 workgroups a split every 12 block pairs
-// (384 tokens) is best - kv 776: 13.2 -> 12.1 us for one sequence, 14.3 -> 13.6 us for 8;
-// kv 2056: 18.7 -> 13.7 us; kv 4104: 17.7 -> 16.2 us - while 128 workgroups of kv 776 lose
-// (15.4 -> 16.0 us) and want 24 pairs per split; 8 workgroups of kv 4104 run 2.7x faster with 8
-// splits and one 16k-token sequence 6x faster with 16.  An in-launch merge by the last workgroup
-// to arrive was measured too: device-scope fences cost more than the merge launch, and with
-// write-through partials it still loses to it (kv 4104, one sequence: 20.4 vs 16.2 us).
-// Rule: aim at one workgroup per CU, at least 12 pairs per split while the chip is less than a
-// quarter full, 24 beyond, at most 16 splits.
+// Number of KV splits of the throughput shape (4 waves).  A split costs a second (merge) launch
+// and a round trip of the partial results, about 2.5 us, so it only pays when the workgroups are
+// few AND long.  Rule: aim at one workgroup per CU, at least 12 pairs per split while the chip is
+// less than a quarter full, 24 beyond, at most 16 splits.
 static int choose_splits(int num_seqs, int num_kv_heads, int max_seq_len) {
-  const int forced = env_int("PE_DECODE_SPLITS", 0);
   const int n_pairs = (max_seq_len + 31) / 32;
   const int cap = split_cap(max_seq_len);
-  if (forced > 0) return forced < cap ? forced : cap;
   static const int min_pairs_env = env_int("PE_DEC_SPLIT_MIN_PAIRS", 0);
   const int64_t wgs = (int64_t)num_seqs * num_kv_heads;
   const int64_t target = 256;  // one workgroup per CU
@@ -483,6 +496,49 @@ static int choose_splits(int num_seqs, int num_kv_heads, int max_seq_len) {
   if (splits < 1) splits = 1;
   if (splits > max_splits) splits = max_splits;
   return splits;
+}
+
+// LDS of the in-workgroup merge: o[waves][gqa][head_size + 4] + m, l [waves][16] (f32)
+static size_t merge_lds_bytes(int waves, int gqa, int head_size) {
+  return ((size_t)waves * gqa * (head_size + 4) + 2 * (size_t)waves * 16) * 4;
+}
+
+// Workgroup width and split count of a launch.
+//   Small launches are bound by latency, not bandwidth: a wave that walks its block pairs one
+//   memory round trip (~1.7 us) after the other is what takes the time, and one CU cannot pull
+//   more than ~100 GB/s however many waves it runs.  While the whole launch has at most 2048
+//   block pairs (the wave slots of the chip at two waves per SIMD) every pair gets a wave of its
+//   own: 8-wave workgroups, one split per 8 pairs (at most 16; the merge launch reads all
+//   partials in one round trip).  Measured on MI355X, graph-replayed, us per launch before ->
+//   after: 1 sequence x 8 KV heads, kv 776: 11.4 -> 8.1; OPT-125m geometry, kv 1074: 10.1 -> 7.4;
+//   8 sequences: 12.3 -> 9.9; 64 sequences x 1 KV head (one rank of TP=8), kv 776: 13.6 -> 10.5;
+//   1 sequence of kv 4104: 16.3 -> 11.5.
+//   Larger launches keep the throughput shape: 4 waves (two workgroups per CU, two tiles in
+//   flight per wave), splits only while the chip is not full.
+//   Experiment overrides: PE_DECODE_WAVES (4/8/16), PE_DECODE_SPLITS.
+static void choose_shape(int num_seqs, int num_heads, int num_kv_heads, int head_size,
+                         int max_seq_len, int* waves, int* splits) {
+  const int n_pairs = (max_seq_len + 31) / 32;
+  const int cap = split_cap(max_seq_len);
+  const int64_t wgs = (int64_t)num_seqs * num_kv_heads;
+  static const int64_t latency_pairs = env_int("PE_DEC_LATENCY_PAIRS", 2048);
+  *waves = DEC_WAVES;
+  if (wgs * n_pairs <= latency_pairs && n_pairs > DEC_WAVES) {
+    *waves = 8;
+    int sp = (n_pairs + 7) / 8;
+    if (sp > 16) sp = 16;
+    if (sp > cap) sp = cap;
+    *splits = sp;
+  } else {
+    *splits = choose_splits(num_seqs, num_kv_heads, max_seq_len);
+  }
+  const int forced_w = env_int("PE_DECODE_WAVES", 0);
+  if (forced_w == 4 || forced_w == 8 || forced_w == 16) *waves = forced_w;
+  const int forced_s = env_int("PE_DECODE_SPLITS", 0);
+  if (forced_s > 0) *splits = forced_s < cap ? forced_s : cap;
+  while (*waves > DEC_WAVES &&
+         merge_lds_bytes(*waves, num_heads / num_kv_heads, head_size) > 64 * 1024)
+    *waves /= 2;
 }
 
 static bool mfma_path_ok(int num_heads, int num_kv_heads, int head_size, int block_size,
@@ -548,7 +604,8 @@ static int decode_impl(void* out, const void* query, const void* key_cache, cons
 
   if (mfma_path_ok(num_heads, num_kv_heads, head_size, block_size, dtype, q_stride,
                    kv_block_stride, kv_head_stride)) {
-    const int splits = choose_splits(num_seqs, num_kv_heads, max_seq_len);
+    int splits = 1, waves = DEC_WAVES;
+    choose_shape(num_seqs, num_heads, num_kv_heads, head_size, max_seq_len, &waves, &splits);
     float* ws = static_cast<float*>(workspace);
     if (splits > 1) {
       const int64_t need = (int64_t)splits * num_seqs * num_heads * ws_stride(head_size) * 4;
@@ -557,26 +614,39 @@ static int decode_impl(void* out, const void* query, const void* key_cache, cons
                  (long long)workspace_bytes);
     }
     dim3 grid((unsigned)splits, (unsigned)num_kv_heads, (unsigned)num_seqs);
-#define PE_LAUNCH_DEC(T, HS)                                                                    \
-  hipLaunchKernelGGL((paged_decode_mfma_kernel<T, HS>), grid, dim3(DEC_THREADS), 0, st, (T*)out, \
+    const size_t lds = merge_lds_bytes(waves, num_heads / num_kv_heads, head_size);
+#define PE_LAUNCH_DEC_W(T, HS, W)                                                                \
+  hipLaunchKernelGGL((paged_decode_mfma_kernel<T, HS, W>), grid, dim3(W * 64), lds, st, (T*)out, \
                      ws, (const T*)query, (const T*)key_cache, (const T*)value_cache,            \
                      block_tables, seq_lens, alibi_slopes, num_heads, num_kv_heads,              \
                      max_num_blocks_per_seq, q_stride, kv_block_stride, kv_head_stride, scale,   \
                      splits, (const T*)new_key, (const T*)new_value, new_slots, new_k_stride,     \
                      new_v_stride, num_slots, (T*)key_cache, (T*)value_cache)
+#define PE_LAUNCH_DEC(T, HS)                               \
+  do {                                                     \
+    if (waves == 16) PE_LAUNCH_DEC_W(T, HS, 16);           \
+    else if (waves == 8) PE_LAUNCH_DEC_W(T, HS, 8);        \
+    else PE_LAUNCH_DEC_W(T, HS, DEC_WAVES);                \
+  } while (0)
     PE_DISPATCH_16(dtype, T, {
       if (head_size == 64) PE_LAUNCH_DEC(T, 64);
       else if (head_size == 128) PE_LAUNCH_DEC(T, 128);
       else PE_LAUNCH_DEC(T, 256);
     });
 #undef PE_LAUNCH_DEC
+#undef PE_LAUNCH_DEC_W
     if (int rc = check_launch("paged_decode")) return rc;
     if (splits > 1) {
-      PE_DISPATCH_16(dtype, T,
-                     hipLaunchKernelGGL(paged_decode_merge_kernel<T>,
-                                        dim3((unsigned)num_heads, (unsigned)num_seqs),
-                                        dim3(head_size <= 64 ? 64 : 128), 0, st, (T*)out, ws,
-                                        num_heads, head_size, splits));
+#define PE_LAUNCH_MERGE(T, MS)                                                                   \
+  hipLaunchKernelGGL((paged_decode_merge_kernel<T, MS>), dim3((unsigned)num_heads, (unsigned)num_seqs), \
+                     dim3(head_size <= 64 ? 64 : 128), 0, st, (T*)out, ws, num_heads, head_size, splits)
+      PE_DISPATCH_16(dtype, T, {
+        if (splits <= 4) PE_LAUNCH_MERGE(T, 4);
+        else if (splits <= 8) PE_LAUNCH_MERGE(T, 8);
+        else if (splits <= 16) PE_LAUNCH_MERGE(T, 16);
+        else PE_LAUNCH_MERGE(T, 64);
+      });
+#undef PE_LAUNCH_MERGE
       if (int rc = check_launch("paged_decode_merge")) return rc;
     }
     return PE_OK;
