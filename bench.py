@@ -106,6 +106,10 @@ def parse():
     ap.add_argument("--per-request-scheduler", action="store_true",
                     help="drive the decode steps through the per-request scheduler / metadata builder "
                          "(the reference's shape of the host code) instead of the vectorised ones")
+    ap.add_argument("--host-tables", action="store_true",
+                    help="vectorised scheduler with the block tables kept on the host and uploaded "
+                         "every decode step (default: tables resident on the GPU, one int per "
+                         "sequence uploaded per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--alt-evict", type=float, default=0.5,
                     help="second eviction fraction measured after the timed region and reported under "
@@ -253,7 +257,8 @@ class Workload:
         a, bs = self.a, self.bs
         B, L0 = a.num_prompts, a.input_len
         sched = BatchEvictionScheduler(bs, self.num_blocks, self.cfg, max_seqs=B,
-                                       max_blocks_per_seq=self.blocks_per_seq_full + 2)
+                                       max_blocks_per_seq=self.blocks_per_seq_full + 2,
+                                       device=None if a.host_tables else self.dev)
         rids = [f"req{i}" for i in range(B)]
         for i, r in enumerate(rids):
             sched.add_request(r, i, L0)

@@ -69,9 +69,13 @@ enum {
   PE_DIAG_DECODE_LEN_CLAMPED = 1, /* pe_paged_decode / pe_decode_step: a seq_lens entry exceeded
                                      max_num_blocks_per_seq * block_size (or, on the generic
                                      path, max_seq_len) and was clamped                        */
-  PE_DIAG_SCORE_ROW_FULL = 2      /* pe_evict_select_compact: a sequence's score row already
+  PE_DIAG_SCORE_ROW_FULL = 2,     /* pe_evict_select_compact: a sequence's score row already
                                      held score_table_width entries; the new block's score was
                                      not appended                                              */
+  PE_DIAG_TABLE_STATE_MISMATCH = 4 /* pe_table_state_advance: the step's token does not fall into
+                                     the last block of the device-resident row (host and device
+                                     counters disagree, or the row is full); the token's slot
+                                     was reported as -1 (not cached)                           */
 };
 int pe_device_diagnostics(unsigned int* flags_out, int reset);
 
@@ -330,6 +334,53 @@ int pe_evict_select_compact(int32_t* rmv_idx_out, int32_t* out_tables,
                             const void* value_cache, int64_t kv_block_stride,
                             int num_kv_heads, int head_size, const float* new_scores,
                             int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Device-resident block tables of the running decode batch (the "eviction scheduler" half that
+ * lives on the GPU).  State, caller-owned device arrays in batch order:
+ *     tables     int32 [capacity, max_blocks]  block ids of batch slot b, zero padded
+ *     num_blocks int32 [capacity]              entries in use
+ *     kv_lens    int32 [capacity]              tokens physically held (BlockTable._num_cached_slots,
+ *                                              vllm/core/block/block_table.py:119-126,183-196)
+ *     seq_lens   int32 [capacity]              logical length (_num_full_slots)
+ * The host uploads a row only when a sequence joins the batch; per step it sends one int32 per
+ * sequence (the id of a newly allocated block, or -1), so the bytes crossing PCIe per step do
+ * not depend on the table width.
+ *
+ * pe_table_state_advance: one decode step's append for every batch slot - replaces, on the
+ *   device, BlockTable.append_token_ids (block_table.py:136-196), the decode arm of
+ *   _compute_slot_mapping (vllm/attention/backends/torch_cuda_sdpa.py:591-598) and the
+ *   kv-length adjustment of ModelInputForGPUBuilder._compute_lens
+ *   (vllm/worker/model_runner.py:538-543).  new_blocks[b] >= 0 is appended to row b; both
+ *   lengths grow by one; slot_mapping_out[b] = last block * block_size + (kv_len-1) % block_size;
+ *   attn_kv_lens_out[b] = the physical length attention must see this step: kv_len minus the
+ *   tokens this step evicts (evict_rule 0: none; 1: budget type, block_size tokens when
+ *   seq_len > cache_budget and seq_len % block_size == 0 - pass 0 for inverse_key_l2, which never
+ *   removes a block; 2: percentage type, (num_block_merge-1)*block_size tokens when
+ *   seq_len % (block_size*evict_freq) == 0 and kv_len > (initial_blocks+num_block_merge)*block_size).
+ *   last_blocks_out (optional) = id of each row's last block (what a head-sharded caller scores).
+ * pe_evict_select_compact_inplace: pe_evict_select_compact on that state - the victim's column
+ *   is closed inside the row (no second table), num_blocks[b] and kv_lens[b] are updated, and
+ *   freed_blocks_out[b] = the victim's block id (-1: none) for the host's free list.  Victim
+ *   choice, score bookkeeping and zero_slots_out exactly as pe_evict_select_compact.  Every layer
+ *   of the step then reads block_tables with attn_kv_lens.
+ * ---------------------------------------------------------------------------------- */
+int pe_table_state_advance(int32_t* tables, int32_t* num_blocks, int32_t* kv_lens,
+                           int32_t* seq_lens, const int32_t* new_blocks, int batch, int max_blocks,
+                           int64_t* slot_mapping_out, int32_t* attn_kv_lens_out,
+                           int32_t* last_blocks_out, int evict_rule, int cache_budget,
+                           int block_size, int evict_freq, int num_block_merge, int initial_blocks,
+                           void* stream);
+int pe_evict_select_compact_inplace(int32_t* rmv_idx_out, int32_t* freed_blocks_out,
+                                    int64_t* zero_slots_out, int32_t* block_tables,
+                                    int32_t* num_blocks, int32_t* kv_lens, const int32_t* seq_lens,
+                                    const int32_t* victim_override, int batch, int max_blocks,
+                                    int method, int cache_budget, int block_size, int topk_blocks,
+                                    int drop_victim_score, int score_layout, float* score_table,
+                                    int32_t* score_counts, const int32_t* score_rows,
+                                    int score_table_width, const void* value_cache,
+                                    int64_t kv_block_stride, int num_kv_heads, int head_size,
+                                    const float* new_scores, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Decode step of the "percentage" prune type (README-era flags --cache-prune-type percentage

@@ -27,9 +27,16 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), s
     assert lib.pe_version() >= 101
     # workspace helpers are pure host functions
-    # sized for the largest split count a launch may use: one split per 8 block pairs of 32 tokens
-    assert lib.pe_paged_decode_workspace_bytes(64, 32, 8, 128, 16, 776) == 3 * 64 * 32 * (128 + 2) * 4
-    assert lib.pe_paged_decode_workspace_bytes(64, 32, 8, 128, 16, 300) == 0
+    # sized for the largest split count a launch may use: one split per 4 block pairs of 32 tokens,
+    # at most 64
+    assert lib.pe_paged_decode_workspace_bytes(64, 32, 8, 128, 16, 776) == 6 * 64 * 32 * (128 + 2) * 4
+    assert lib.pe_paged_decode_workspace_bytes(64, 32, 8, 128, 16, 100000) == 64 * 64 * 32 * (128 + 2) * 4
+    assert lib.pe_paged_decode_workspace_bytes(64, 32, 8, 128, 16, 220) == 0      # 7 pairs: one split
+    prev = 0
+    for n in range(1, 40000, 97):       # never shrinks as the maximum length grows
+        cur = lib.pe_paged_decode_workspace_bytes(3, 32, 8, 128, 16, n)
+        assert cur >= prev
+        prev = cur
     assert lib.pe_paged_decode_workspace_bytes(0, 32, 8, 128, 16, 776) == 0
     assert lib.pe_prompt_token_select_workspace_bytes(100, 8) == ((100 * 8 * 4 + 255) // 256) * 256 + 800
 

@@ -1,0 +1,171 @@
+"""Device-resident block tables (batch_scheduler.DeviceTableState): what crosses PCIe per decode
+step must not depend on the table width, and a generation driven through the resident tables must
+evict exactly what the host-table form evicts."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BS = 16
+
+
+def _generation(method, prompt_len, budget, n_decode, device_tables, B=6, Hq=8, Hkv=2, D=128, layers=2):
+    from vllm_paged_compression_amd.backend import PagedEvictBackend
+    from vllm_paged_compression_amd.batch_scheduler import BatchEvictionScheduler
+    from vllm_paged_compression_amd.config import CacheConfigView, PagedEvictConfig
+    dev = torch.device("cuda:0")
+    cfg = PagedEvictConfig(True, "budget", method, budget, 3)
+    ccfg = CacheConfigView(BS, cfg)
+    per_seq = (prompt_len + n_decode) // BS + 2
+    nb = B * per_seq + 4
+    impls = [PagedEvictBackend.get_impl_cls()(Hq, D, D ** -0.5, Hkv, None, None, "auto", None, None,
+                                              cache_config=ccfg, prefix=f"model.layers.{i}.self_attn.attn",
+                                              max_num_seqs=B, max_blocks_per_seq=per_seq + 2)
+             for i in range(layers)]
+    kv = [torch.zeros(PagedEvictBackend.get_kv_cache_shape(nb, BS, Hkv, D), dtype=torch.bfloat16, device=dev)
+          for _ in range(layers)]
+    sched = BatchEvictionScheduler(BS, nb, cfg, max_seqs=B, max_blocks_per_seq=per_seq + 2,
+                                   device=dev if device_tables else None)
+    rids = [f"r{i}" for i in range(B)]
+    lens = [prompt_len + 3 * i for i in range(B)]
+    for i, r in enumerate(rids):
+        sched.add_request(r, i, lens[i])
+
+    def builder(inter):
+        runner = SimpleNamespace(device=dev, cache_config=ccfg, pin_memory=False)
+        ib = SimpleNamespace(runner=runner, sliding_window=None, block_size=BS,
+                             chunked_prefill_enabled=False, inter_data_list=inter)
+        return PagedEvictBackend.make_metadata_builder(ib)
+
+    g = torch.Generator(device=dev).manual_seed(3)
+
+    def rnd(T, H):
+        return torch.empty(T, H * D, dtype=torch.bfloat16, device=dev).uniform_(-1, 1, generator=g)
+
+    inter = [SimpleNamespace(request_id=r, is_prompt=True, block_tables={i: sched.get_block_table(r)},
+                             seq_kv_lens={i: sched.get_seq_kv_len(r)}, seq_ids=[i], input_tokens=[range(lens[i])],
+                             orig_seq_lens=[lens[i]], seq_lens=[lens[i]], query_lens=[lens[i]], context_lens=[0])
+             for i, r in enumerate(rids)]
+    meta = builder(inter).build(lens, lens, -1, B)
+    T = sum(lens)
+    for li, impl in enumerate(impls):
+        impl.forward(rnd(T, Hq), rnd(T, Hkv), rnd(T, Hkv), kv[li], meta)
+    victims, outs, h2d = [], [], []
+    for _ in range(n_decode):
+        before = sched.device_state.h2d_bytes if device_tables else 0
+        batch = sched.schedule_decode(rids)
+        meta = builder([]).build_decode_batch(batch)
+        q, k, v = rnd(B, Hq), rnd(B, Hkv), rnd(B, Hkv)
+        for li, impl in enumerate(impls):
+            o = impl.forward(q, k, v, kv[li], meta)
+            if li == 0:
+                outs.append(o.clone())
+        got = impls[0].get_rmv_block_idx()
+        victims.append(dict(got))
+        sched.commit(got)
+        if device_tables:
+            h2d.append(sched.device_state.h2d_bytes - before)
+    tables = [sched.get_block_table(r) for r in rids]
+    if device_tables:
+        st = sched.device_state
+        n = st.num_blocks[:B].cpu().tolist()
+        assert [st.tables[i, :n[i]].cpu().tolist() for i in range(B)] == tables
+    torch.cuda.synchronize()
+    return victims, outs, tables, [t.cpu() for t in kv], h2d
+
+
+@pytest.mark.parametrize("method", ["streamingLLM", "streamingLLM-1", "global", "local", "inverse_key_l2"])
+def test_device_tables_match_host_tables(method):
+    import random
+    from vllm_paged_compression_amd import ops
+    random.seed(1234)
+    a = _generation(method, 150, 128, 40, device_tables=False)
+    random.seed(1234)
+    b = _generation(method, 150, 128, 40, device_tables=True)
+    assert a[0] == b[0], "victims differ"
+    assert a[2] == b[2], "final tables differ"
+    for x, y in zip(a[1], b[1]):
+        assert torch.equal(x, y)                 # same kernels on the same tables: bit-identical
+    for x, y in zip(a[3], b[3]):
+        assert torch.equal(x, y)                 # KV cache bytes
+    if method != "inverse_key_l2":
+        assert sum(len(v) for v in a[0]) >= 6
+    ops.check_device_diagnostics()
+
+
+def test_device_tables_h2d_bytes_independent_of_table_width():
+    """Steady-state decode steps upload 4 bytes per sequence whatever the prompt length (the host
+    form uploads the whole [B, M] matrix every step)."""
+    short = _generation("streamingLLM", 300, 256, 20, device_tables=True)[4]
+    long = _generation("streamingLLM", 2400, 2048, 20, device_tables=True)[4]
+    B = 6
+    # the first step loads the rows (the batch was just formed); every later step sends the
+    # new-block ids only
+    assert short[0] > 4 * B and long[0] > short[0]
+    assert set(short[1:]) == {4 * B} and set(long[1:]) == {4 * B}
+
+
+def test_table_state_kernels_against_host_model(oracle):
+    """pe_table_state_advance + pe_evict_select_compact_inplace on random states against a plain
+    Python model (the same arithmetic as block_table.EvictBlockTable / the oracle's streaming
+    decision)."""
+    from vllm_paged_compression_amd import ops
+    rng = np.random.default_rng(5)
+    B, M, budget = 37, 24, 128
+    dev = torch.device("cuda:0")
+    n_blocks = rng.integers(9, 12, B)
+    kv = np.array([rng.integers((n - 1) * BS, n * BS + 1) for n in n_blocks])   # may sit on a boundary
+    L = kv + rng.integers(0, 200, B)
+    tables = np.zeros((B, M), dtype=np.int32)
+    nxt = 1000
+    for b in range(B):
+        tables[b, :n_blocks[b]] = rng.permutation(500)[:n_blocks[b]] + 1
+    new_blocks = np.full(B, -1, dtype=np.int32)
+    for b in range(B):
+        if kv[b] == n_blocks[b] * BS:           # full: the step's token needs a fresh block
+            new_blocks[b] = nxt
+            nxt += 1
+    t = lambda a, dt=torch.int32: torch.tensor(np.asarray(a), dtype=dt, device=dev)  # noqa: E731
+    d_tab, d_n, d_kv, d_L = t(tables), t(n_blocks), t(kv), t(L)
+    slots = torch.empty(B, dtype=torch.int64, device=dev)
+    attn = torch.empty(B, dtype=torch.int32, device=dev)
+    last = torch.empty(B, dtype=torch.int32, device=dev)
+    ops.table_state_advance(d_tab, d_n, d_kv, d_L, t(new_blocks), B, slots, attn, last, 1, budget, BS)
+    exp_tab, exp_n = tables.copy(), n_blocks.copy()
+    exp_slots, exp_attn = [], []
+    for b in range(B):
+        if new_blocks[b] >= 0:
+            exp_tab[b, exp_n[b]] = new_blocks[b]
+            exp_n[b] += 1
+        k1, L1 = kv[b] + 1, L[b] + 1
+        exp_slots.append(oracle.decode_slot(exp_tab[b, :exp_n[b]].tolist(), k1 - 1, BS))
+        exp_attn.append(k1 - (BS if oracle.decode_trigger(L1, budget, BS) else 0))
+    assert d_tab.cpu().numpy().tolist() == exp_tab.tolist()
+    assert d_n.cpu().tolist() == exp_n.tolist() and d_kv.cpu().tolist() == (kv + 1).tolist()
+    assert d_L.cpu().tolist() == (L + 1).tolist()
+    assert slots.cpu().tolist() == exp_slots and attn.cpu().tolist() == exp_attn
+    assert last.cpu().tolist() == [int(exp_tab[b, exp_n[b] - 1]) for b in range(B)]
+    # in-place streamingLLM eviction on that state
+    rmv, freed, _ = ops.evict_select_compact_inplace(d_tab, d_n, d_kv, d_L, B, "streamingLLM", budget, BS)
+    exp_rmv, _ = oracle.decode_streaming((L + 1).tolist(), [r.tolist() for r in exp_tab], budget, BS,
+                                         "streamingLLM")
+    assert rmv.cpu().tolist() == exp_rmv
+    for b in range(B):
+        row = exp_tab[b, :exp_n[b]].tolist()
+        if exp_rmv[b] >= 0:
+            assert int(freed[b]) == row[1]
+            del row[1]
+        else:
+            assert int(freed[b]) == -1
+        got_n = int(d_n[b])
+        assert got_n == len(row) and d_tab[b, :got_n].cpu().tolist() == row
+        assert not d_tab[b, got_n:].any()
+        assert int(d_kv[b]) == kv[b] + 1 - (BS if exp_rmv[b] >= 0 else 0)
+    # a token that cannot fall into the row's last block is flagged, not written
+    bad_n = t(np.full(B, 2))
+    ops.table_state_advance(d_tab, bad_n, d_kv, d_L, t(np.full(B, -1)), B, slots, attn, None, 0, 0, BS)
+    assert ops.device_diagnostics(reset=True) == ops.DIAG_TABLE_STATE_MISMATCH
+    assert (slots == -1).all()

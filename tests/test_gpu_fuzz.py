@@ -22,7 +22,7 @@ def _rand(T, H, g, scale):
     return ((torch.rand(T, H * D, generator=g) * 2 - 1) * scale).to(torch.bfloat16)
 
 
-@pytest.mark.parametrize("vectorised", [False, True])
+@pytest.mark.parametrize("vectorised", [False, True, "device"])
 @pytest.mark.parametrize("method,seed,evict_before_prefill", [
     ("streamingLLM", 0, False), ("streamingLLM-1", 1, False), ("global", 2, False), ("global", 3, False),
     ("local", 4, False), ("streamingLLM", 5, True), ("global", 6, True),
@@ -53,7 +53,12 @@ def test_continuous_batching_fuzz(oracle, method, seed, evict_before_prefill, ve
     vc_cpu = [torch.zeros(nb, HKV, D, BS, dtype=torch.bfloat16) for _ in range(LAYERS)]
     ref_sched = EvictionScheduler(EvictBlockSpaceManager(BS, nb, cfg, watermark=0.0))
     bm = ref_sched.block_manager
-    vec_sched = BatchEvictionScheduler(BS, nb, cfg, max_seqs=8, max_blocks_per_seq=40) if vectorised else None
+    if vectorised == "device" and pct:
+        pytest.skip("the percentage prune type keeps its tables on the host")
+    # "device": the vectorised scheduler with the running batch's tables resident on the GPU
+    vec_sched = BatchEvictionScheduler(BS, nb, cfg, max_seqs=8, max_blocks_per_seq=40,
+                                       device="cuda:0" if vectorised == "device" else None) \
+        if vectorised else None
 
     def builder(inter):
         runner = SimpleNamespace(device=torch.device("cuda:0"), cache_config=ccfg, pin_memory=False)
@@ -226,6 +231,16 @@ def test_continuous_batching_fuzz(oracle, method, seed, evict_before_prefill, ve
                 if vec_sched is not None:
                     assert vec_sched.get_block_table(rid) == tbls[i]
                     assert vec_sched.get_seq_kv_len(rid) == bm.get_seq_kv_len(seq_of[rid])
+            if vec_sched is not None and vec_sched.device_state is not None:
+                # the resident rows hold exactly the committed tables and counters
+                st = vec_sched.device_state
+                dev_t, dev_n = st.tables[:B].cpu(), st.num_blocks[:B].cpu().tolist()
+                assert dev_n == [len(t) for t in tbls]
+                for i in range(B):
+                    assert dev_t[i, :dev_n[i]].tolist() == tbls[i]
+                    assert not dev_t[i, dev_n[i]:].any()
+                assert st.kv_lens[:B].cpu().tolist() == [bm.get_seq_kv_len(seq_of[r]) for r in running]
+                assert st.seq_lens[:B].cpu().tolist() == L
             for rid in list(running):
                 remaining[rid] -= 1
                 if remaining[rid] == 0:

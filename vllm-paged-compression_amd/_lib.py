@@ -56,6 +56,14 @@ SIGNATURES = {
                                         c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                         c_int, c_void_p, c_int64, c_int, c_int, c_void_p, c_int,
                                         c_void_p]),
+    "pe_table_state_advance": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                       c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                       c_int, c_void_p]),
+    "pe_evict_select_compact_inplace": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                                c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                                c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                                c_void_p, c_int, c_void_p, c_int64, c_int, c_int,
+                                                c_void_p, c_int, c_void_p]),
     "pe_merge_blocks_value_l2": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                          c_int, c_int, c_int, c_int, c_int64, c_int64, c_int,
                                          c_void_p]),

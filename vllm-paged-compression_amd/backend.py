@@ -348,6 +348,22 @@ class PagedEvictMetadataBuilder(_BuilderBase):
         if seq_kv_lens is None:
             seq_kv_lens = adjust_seq_kv_lens(self.paged_evict_config, batch.seq_lens, batch.kv_lens, bs)
         B = len(batch.request_ids)
+        st = getattr(batch, "device_state", None)
+        if st is not None:
+            # device-resident tables: the step's append, slot mapping and kv lengths were computed
+            # on the GPU by the scheduler's advance launch; nothing is uploaded here.  The prefix
+            # sums and context lengths, which no decode launch reads, are left out.
+            kv_list = np.asarray(seq_kv_lens, dtype=np.int64).tolist()
+            meta = PagedEvictMetadata(
+                num_prefills=0, slot_mapping=st.slot_mapping[:B], multi_modal_placeholder_index_maps=None,
+                num_prefill_tokens=0, num_decode_tokens=B, seq_lens=batch.seq_lens.tolist(),
+                seq_lens_tensor=st.seq_lens[:B], max_query_len=1, max_prefill_seq_len=0,
+                max_decode_seq_len=int(batch.seq_lens.max()) if B else 0, query_start_loc=None,
+                seq_start_loc=None, context_lens_tensor=None, block_tables=st.tables[:B],
+                use_cuda_graph=False, seq_kv_lens=kv_list, seq_kv_lens_tensor=st.attn_kv_lens[:B],
+                reqid_mapping_blocktables=None)
+            meta._pe_batch = batch
+            return meta
         device = self.runner.device
         i32 = np.int32
         kv = np.asarray(seq_kv_lens, dtype=np.int64)
@@ -782,7 +798,7 @@ class PagedEvictImpl(_ImplBase):
         if batch is not None:       # array view of the step (vectorised scheduler)
             L = batch.seq_lens
             table_lens = batch.table_lens.astype(np.int64)
-            table_of = lambda i: batch.block_tables[i, :table_lens[i]].tolist()  # noqa: E731
+            table_of = batch.table_row
         else:                       # per-request mapping of the reference's builder
             L = np.asarray(seq_lens, dtype=np.int64)
             mapping = meta.reqid_mapping_blocktables
@@ -797,6 +813,16 @@ class PagedEvictImpl(_ImplBase):
         if self._score_table is not None:
             # a decode step lists every running sequence: whoever is absent has finished
             self._score_table.retain_only(keys)
+        st = getattr(batch, "device_state", None) if batch is not None else None
+        if st is not None and not (self.compat.per_layer_decision or self.compat.block_table_slice_in_loop
+                                   or self.compat.streaming_decode_original_table):
+            dec = self._decode_decision_device(st, dm, L, table_of, keys, req_ids, value_cache)
+            step["decode"] = dec
+            return dec
+        if st is not None:
+            raise NotImplementedError("device-resident block tables take one decision per step and "
+                                      "compact in place: not available with the per-layer / "
+                                      "in-loop-slice / original-table compatibility switches")
         over_np = L > cfg.cache_budget
         trig_np = over_np & (L % bs == 0)
         over, trig = over_np.tolist(), trig_np.tolist()
@@ -894,6 +920,87 @@ class PagedEvictImpl(_ImplBase):
                 dec["readback"] = staging.AsyncReadback(dec["rmv"])
         if not self.compat.per_layer_decision:
             step["decode"] = dec
+        return dec
+
+    def _decode_decision_device(self, st, dm, L: np.ndarray, table_of, keys, req_ids,
+                                value_cache) -> Dict[str, Any]:
+        """The budget-type decision on device-resident tables (``DeviceTableState``): the same
+        launch as ``_decode_decision`` takes, but the victim's column is closed inside the
+        resident row, so there is no second table and nothing about the tables is uploaded.
+        ``dm.block_tables`` IS the resident array: every layer of the step reads it after this
+        launch, with ``dm.seq_kv_lens_tensor`` (already shortened by the scheduler's advance)."""
+        cfg = self.paged_evict_config
+        bs = self.cache_config.block_size
+        method = cfg.evict_method
+        dev = st.tables.device
+        B = len(req_ids)
+        over_np = L > cfg.cache_budget
+        trig_np = over_np & (L % bs == 0)
+        trig = trig_np.tolist()
+        any_trig = bool(trig_np.any())
+        dec: Dict[str, Any] = {"rmv": None, "tables": None, "zero_slots": None, "host_rmv": None,
+                               "req_ids": req_ids if any_trig else None}
+        if method == "inverse_key_l2":
+            slots = []
+            for i, o in enumerate(over_np.tolist()):
+                if not o:
+                    continue
+                ids = table_of(i)
+                slots.append(ids[random.randint(1, len(ids) - 2)] * bs + random.randint(0, bs - 1))
+            if slots:
+                dec["zero_slots"] = staging.upload([np.asarray(slots, dtype=np.int64)], dev)[0]
+            return dec
+        if method in ("streamingLLM", "streamingLLM-1"):
+            need_zero = method == "streamingLLM-1" and bool((over_np & ~trig_np).any())
+            if any_trig or need_zero:
+                _, _, zero = ops.evict_select_compact_inplace(
+                    st.tables, st.num_blocks, st.kv_lens, st.seq_lens, B, method, cfg.cache_budget, bs)
+                dec["zero_slots"] = zero
+                dec["host_rmv"] = {i: (req_ids[i], 1) for i, t in enumerate(trig) if t}
+            return dec
+        if not any_trig:
+            return dec
+        override = None
+        score_kw: Dict[str, Any] = {}
+        if self.compat.random_victim:
+            ov = []
+            for i, t in enumerate(trig):
+                if not t:
+                    ov.append(-1)
+                    continue
+                n = len(table_of(i))
+                end = 1 + cfg.topk_blocks if method == "local" else n - 1
+                ov.append(random.randint(1, end - 1))
+            override = staging.upload_i32(ov, dev)
+            dec["host_rmv"] = {i: (req_ids[i], r) for i, r in enumerate(ov) if r >= 0}
+        elif self._tp_size() > 1 and not self._tp_exact_scores():
+            raise NotImplementedError("device-resident tables under tensor parallelism need the "
+                                      "rank-invariant scores (CompatFlags.score_flat_cache_view off)")
+        else:
+            table = self._table(dev)
+            if st.score_rows_key != st.key or st.score_rows is None:
+                st.score_rows = staging.upload_i32([table.row_of(k) for k in keys], dev)
+                st.score_rows_key = st.key
+            table.flush_new_rows()
+            new_scores = None
+            if self._tp_exact_scores():
+                sums = ops.block_token_norm_sums(value_cache, st.last_blocks[:B], B, ops.SCORE_CACHE,
+                                                 value_cache.shape[1], value_cache.shape[2], bs,
+                                                 block_stride=value_cache.stride(0))
+                self._reduce_token_sums(sums)
+                new_scores = ops.block_score_from_token_sums(sums, B, bs, self.total_num_kv_heads,
+                                                             value_cache.dtype)
+            score_kw = dict(drop_victim_score=not self.compat.keep_victim_score,
+                            score_layout=(ops.SCORE_CACHE_FLAT if self.compat.score_flat_cache_view
+                                          else ops.SCORE_CACHE),
+                            score_table=table.scores, score_counts=table.counts,
+                            score_rows=st.score_rows, value_cache=value_cache, new_scores=new_scores)
+        rmv, _, _ = ops.evict_select_compact_inplace(
+            st.tables, st.num_blocks, st.kv_lens, st.seq_lens, B, method, cfg.cache_budget, bs,
+            cfg.topk_blocks, victim_override=override, **score_kw)
+        if dec["host_rmv"] is None:
+            dec["rmv"] = rmv
+            dec["readback"] = staging.AsyncReadback(rmv)
         return dec
 
     def _decode_decision_percentage(self, dm, L: np.ndarray, table_lens: np.ndarray,

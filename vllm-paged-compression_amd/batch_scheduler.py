@@ -28,16 +28,92 @@ class DecodeBatch:
     request_ids: List[str]
     seq_ids: List[int]
     rows: np.ndarray          # state rows of the sequences
-    block_tables: np.ndarray  # int32 [B, M] (M = longest table), zero padded
+    block_tables: Optional[np.ndarray]  # int32 [B, M] (M = longest table), zero padded; None when
+    #                           the tables live on the device (``device_state``)
     table_lens: np.ndarray    # int32 [B]
     kv_lens: np.ndarray       # int64 [B] physical lengths incl. this step's token
     seq_lens: np.ndarray      # int64 [B] logical lengths incl. this step's token
+    device_state: Optional["DeviceTableState"] = None
+    host_tables: Optional[np.ndarray] = None   # the scheduler's table array (rows = ``rows``)
+
+    def table_row(self, i: int) -> List[int]:
+        """Block ids of batch entry i (host copy)."""
+        n = int(self.table_lens[i])
+        if self.block_tables is not None:
+            return self.block_tables[i, :n].tolist()
+        return self.host_tables[self.rows[i], :n].tolist()
+
+
+class DeviceTableState:
+    """The running batch's block tables and length counters, resident on the GPU in batch order
+    (row b = b-th sequence of the decode batch).
+
+    A row goes up only when the batch composition changes (``load``); a decode step sends one
+    int32 per sequence - the id of a block allocated for it this step, or -1 - and the device
+    appends it, advances both length counters and derives the step's slot mapping and the kv
+    lengths attention must see (``advance``, one launch).  The eviction launch of the step then
+    closes the victim's column inside the row.  ``h2d_bytes`` counts what crossed PCIe."""
+
+    def __init__(self, capacity: int, max_blocks: int, device):
+        import torch
+        self.device = torch.device(device)
+        self.capacity, self.max_blocks = capacity, max_blocks
+        z = lambda *s, dt=torch.int32: torch.zeros(s, dtype=dt, device=self.device)  # noqa: E731
+        self.tables = z(capacity, max_blocks)
+        self.num_blocks, self.kv_lens, self.seq_lens = z(capacity), z(capacity), z(capacity)
+        self.slot_mapping = z(capacity, dt=torch.int64)
+        self.attn_kv_lens, self.last_blocks = z(capacity), z(capacity)
+        self.batch = 0
+        self.key: Optional[Tuple[str, ...]] = None
+        self.h2d_bytes = 0
+        self.loads = 0
+        self.score_rows = None       # device int32 [batch] cached by the backend per batch key
+        self.score_rows_key = None
+
+    def load(self, key, tables: np.ndarray, n_blocks: np.ndarray, kv_lens: np.ndarray,
+             seq_lens: np.ndarray) -> None:
+        """(Re)load rows 0..B-1 from host arrays: the batch composition changed."""
+        from . import staging
+        B, m = tables.shape
+        if B > self.capacity or m > self.max_blocks:
+            raise RuntimeError("DeviceTableState: batch or table wider than the device state")
+        t, nb, kv, sl = staging.upload([np.ascontiguousarray(tables, dtype=np.int32),
+                                        n_blocks.astype(np.int32), kv_lens.astype(np.int32),
+                                        seq_lens.astype(np.int32)], self.device)
+        self.h2d_bytes += tables.nbytes + 12 * B
+        self.loads += 1
+        self.tables[:B].zero_()
+        if m:
+            self.tables[:B, :m].copy_(t)
+        self.num_blocks[:B].copy_(nb)
+        self.kv_lens[:B].copy_(kv)
+        self.seq_lens[:B].copy_(sl)
+        self.batch, self.key = B, key
+
+    def advance(self, new_blocks: np.ndarray, evict_rule: int, cache_budget: int, block_size: int,
+                evict_freq: int = 0, num_block_merge: int = 2, initial_blocks: int = 1) -> None:
+        from . import ops, staging
+        nb = staging.upload_i32(new_blocks, self.device)
+        self.h2d_bytes += 4 * len(new_blocks)
+        ops.table_state_advance(self.tables, self.num_blocks, self.kv_lens, self.seq_lens, nb,
+                                self.batch, self.slot_mapping, self.attn_kv_lens, self.last_blocks,
+                                evict_rule, cache_budget, block_size, evict_freq, num_block_merge,
+                                initial_blocks)
 
 
 class BatchEvictionScheduler:
 
     def __init__(self, block_size: int, num_gpu_blocks: int, paged_evict_config=None,
-                 max_seqs: int = 256, max_blocks_per_seq: int = 512):
+                 max_seqs: int = 256, max_blocks_per_seq: int = 512, device=None):
+        """``device``: keep the running batch's tables on that GPU (``DeviceTableState``): decode
+        steps then upload one int per sequence instead of the table matrix.  The arrays below
+        remain the host's record of who owns which block (free-list accounting, the blocks to
+        release when a request finishes); they are brought up to date by ``commit``.  The
+        percentage prune type keeps the host form."""
+        self.device_state: Optional[DeviceTableState] = None
+        if device is not None and not (paged_evict_config is not None
+                                       and paged_evict_config.cache_prune_type == "percentage"):
+            self.device_state = DeviceTableState(max_seqs, max_blocks_per_seq, device)
         self.block_size = block_size
         self.paged_evict_config = paged_evict_config
         self.num_total_gpu_blocks = num_gpu_blocks
@@ -129,14 +205,37 @@ class BatchEvictionScheduler:
         """Append one slot to every request (block_table.py:136-196) and return the step's view."""
         bs = self.block_size
         rows = self._rows_for(request_ids)
+        st = self.device_state
+        if st is not None and st.key != self._batch_key:
+            # batch composition changed: the device rows are rebuilt from the host's record
+            # (taken before this step's append, which the device applies itself)
+            lens0 = self.n_blocks[rows]
+            m0 = int(lens0.max()) if len(rows) else 0
+            st.load(self._batch_key, self.tables[rows, :m0], lens0, self.num_cached[rows],
+                    self.num_full[rows])
         self.num_full[rows] += 1
         self.num_cached[rows] += 1
         need = np.nonzero(self.num_cached[rows] > self.n_blocks[rows].astype(np.int64) * bs)[0]
+        new_blocks = None
+        if st is not None:
+            new_blocks = np.full(len(rows), -1, dtype=np.int32)
         if len(need):
             r = rows[need]
-            self.tables[r, self.n_blocks[r]] = self._take(len(need))
+            ids = self._take(len(need))
+            self.tables[r, self.n_blocks[r]] = ids
             self.n_blocks[r] += 1
+            if new_blocks is not None:
+                new_blocks[need] = ids
         lens = self.n_blocks[rows]
+        if st is not None:
+            cfg = self.paged_evict_config
+            rule = 0
+            if cfg is not None and cfg.evict_method in ("streamingLLM", "streamingLLM-1", "global", "local"):
+                rule = 1
+            st.advance(new_blocks, rule, cfg.cache_budget if cfg is not None else 0, bs)
+            return DecodeBatch(list(request_ids), self._batch_seq_ids, rows, None, lens.copy(),
+                               self.num_cached[rows], self.num_full[rows], device_state=st,
+                               host_tables=self.tables)
         m = int(lens.max()) if len(rows) else 0
         return DecodeBatch(list(request_ids), self._batch_seq_ids, rows,
                            self.tables[rows, :m], lens.copy(), self.num_cached[rows],

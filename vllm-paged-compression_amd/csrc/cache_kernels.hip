@@ -226,14 +226,15 @@ __global__ void copy_blocks_kernel(void* const* __restrict__ key_ptrs,
 extern "C" {
 
 const char* pe_last_error(void) { return pe::g_last_error; }
-int pe_version(void) { return 102; }  // 102: pe_paged_decode_noalloc, pe_device_diagnostics
+int pe_version(void) { return 103; }  // 103: device-resident table state (pe_table_state_advance, ..._inplace)
 
 int pe_device_diagnostics(unsigned int* flags_out, int reset) {
   PE_REQUIRE(flags_out != nullptr, PE_ERR_INVALID_ARG, "device_diagnostics: null pointer");
-  unsigned int a = 0, b = 0;
+  unsigned int a = 0, b = 0, c = 0;
   if (int rc = pe::decode_diag_fetch(&a, reset)) return rc;
   if (int rc = pe::evict_diag_fetch(&b, reset)) return rc;
-  *flags_out = a | b;
+  if (int rc = pe::state_diag_fetch(&c, reset)) return rc;
+  *flags_out = a | b | c;
   return PE_OK;
 }
 

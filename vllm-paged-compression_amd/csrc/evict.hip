@@ -205,15 +205,19 @@ __global__ __launch_bounds__(64) void block_score_from_sums_kernel(float* __rest
 // and written by wave 0.
 template <typename T>
 __global__ __launch_bounds__(SCORE_THREADS) void evict_select_compact_kernel(
-    int32_t* __restrict__ rmv_idx_out, int32_t* __restrict__ out_tables,
-    int64_t* __restrict__ zero_slots_out, const int32_t* __restrict__ block_tables,
-    const int32_t* __restrict__ seq_lens, const int32_t* __restrict__ num_blocks,
+    int32_t* __restrict__ rmv_idx_out, int32_t* out_tables,
+    int64_t* __restrict__ zero_slots_out, const int32_t* block_tables,
+    const int32_t* __restrict__ seq_lens, const int32_t* num_blocks,
     const int32_t* __restrict__ victim_override, int batch, int max_blocks, int out_width,
     int method, int cache_budget, int block_size, int topk_blocks, int drop_victim_score, int compat_q1,
     int score_layout, float* __restrict__ score_table, int32_t* __restrict__ score_counts,
     const int32_t* __restrict__ score_rows, int score_table_width,
     const T* __restrict__ value_cache, int64_t kv_block_stride, int num_kv_heads, int head_size,
-    const float* __restrict__ new_scores) {
+    const float* __restrict__ new_scores, int32_t* n_blocks_io, int32_t* kv_lens_io,
+    int32_t* __restrict__ freed_out) {
+  // n_blocks_io != nullptr selects the in-place form (device-resident tables): out_tables is
+  // block_tables itself, the victim's column is closed inside the row, the row's block count
+  // and physical length are updated and the victim's block id is reported in freed_out.
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* norms = reinterpret_cast<float*>(smem);
   float* means = norms + block_size * num_kv_heads;
@@ -313,7 +317,31 @@ __global__ __launch_bounds__(SCORE_THREADS) void evict_select_compact_kernel(
       rmv_idx_out[b] = rmv;
       if (zero_slots_out) zero_slots_out[b] = zslot;
     }
-    if (out_tables != nullptr && w > 0) {
+    if (n_blocks_io != nullptr) {
+      int32_t* r = out_tables + (int64_t)b * max_blocks;  // == row, writable
+      const int n = num_blocks[b];
+      if (rmv >= 0 && rmv < n) {
+        const int32_t victim = r[rmv];
+        // shift [rmv+1, n) left by one, a chunk at a time: all reads of a chunk complete before
+        // its writes, and a later chunk only reads entries no earlier chunk has written
+        for (int base = rmv; base < n - 1; base += blockDim.x) {
+          const int j = base + threadIdx.x;
+          int32_t v = 0;
+          if (j < n - 1) v = r[j + 1];
+          __syncthreads();
+          if (j < n - 1) r[j] = v;
+          __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+          r[n - 1] = 0;
+          n_blocks_io[b] = n - 1;
+          kv_lens_io[b] -= block_size;
+          freed_out[b] = victim;
+        }
+      } else if (threadIdx.x == 0) {
+        freed_out[b] = -1;
+      }
+    } else if (out_tables != nullptr && w > 0) {
       int32_t* o = out_tables + (int64_t)b * w;
       if (!compat_q1 || b == 0) {
         for (int j = threadIdx.x; j < w; j += blockDim.x) {
@@ -411,15 +439,16 @@ int pe_block_score_from_token_sums(float* scores_out, const float* sums, int n_b
   return check_launch("block_score_from_token_sums");
 }
 
-int pe_evict_select_compact(int32_t* rmv_idx_out, int32_t* out_tables, int64_t* zero_slots_out,
-                            const int32_t* block_tables, const int32_t* seq_lens,
-                            const int32_t* num_blocks, const int32_t* victim_override, int batch,
-                            int max_blocks, int out_width, int method, int cache_budget, int block_size,
-                            int topk_blocks, int drop_victim_score, int compat_q1,
-                            int score_layout, float* score_table, int32_t* score_counts,
-                            const int32_t* score_rows, int score_table_width,
-                            const void* value_cache, int64_t kv_block_stride, int num_kv_heads,
-                            int head_size, const float* new_scores, int dtype, void* stream) {
+static int evict_select_impl(int32_t* rmv_idx_out, int32_t* out_tables, int64_t* zero_slots_out,
+                             const int32_t* block_tables, const int32_t* seq_lens,
+                             const int32_t* num_blocks, const int32_t* victim_override, int batch,
+                             int max_blocks, int out_width, int method, int cache_budget,
+                             int block_size, int topk_blocks, int drop_victim_score, int compat_q1,
+                             int score_layout, float* score_table, int32_t* score_counts,
+                             const int32_t* score_rows, int score_table_width,
+                             const void* value_cache, int64_t kv_block_stride, int num_kv_heads,
+                             int head_size, const float* new_scores, int dtype, void* stream,
+                             int32_t* n_blocks_io, int32_t* kv_lens_io, int32_t* freed_out) {
   using namespace pe;
   PE_REQUIRE(batch >= 0, PE_ERR_INVALID_ARG, "negative batch");
   if (batch == 0) return PE_OK;
@@ -463,8 +492,134 @@ int pe_evict_select_compact(int32_t* rmv_idx_out, int32_t* out_tables, int64_t* 
                                      block_size, topk_blocks, drop_victim_score, compat_q1,
                                      score_layout, score_table, score_counts, score_rows,
                                      score_table_width, (const T*)value_cache, kv_block_stride,
-                                     num_kv_heads, head_size, new_scores));
+                                     num_kv_heads, head_size, new_scores, n_blocks_io, kv_lens_io,
+                                     freed_out));
   return check_launch("evict_select_compact");
+}
+
+int pe_evict_select_compact(int32_t* rmv_idx_out, int32_t* out_tables, int64_t* zero_slots_out,
+                            const int32_t* block_tables, const int32_t* seq_lens,
+                            const int32_t* num_blocks, const int32_t* victim_override, int batch,
+                            int max_blocks, int out_width, int method, int cache_budget, int block_size,
+                            int topk_blocks, int drop_victim_score, int compat_q1,
+                            int score_layout, float* score_table, int32_t* score_counts,
+                            const int32_t* score_rows, int score_table_width,
+                            const void* value_cache, int64_t kv_block_stride, int num_kv_heads,
+                            int head_size, const float* new_scores, int dtype, void* stream) {
+  return evict_select_impl(rmv_idx_out, out_tables, zero_slots_out, block_tables, seq_lens,
+                           num_blocks, victim_override, batch, max_blocks, out_width, method,
+                           cache_budget, block_size, topk_blocks, drop_victim_score, compat_q1,
+                           score_layout, score_table, score_counts, score_rows, score_table_width,
+                           value_cache, kv_block_stride, num_kv_heads, head_size, new_scores, dtype,
+                           stream, nullptr, nullptr, nullptr);
+}
+
+int pe_evict_select_compact_inplace(int32_t* rmv_idx_out, int32_t* freed_blocks_out,
+                                    int64_t* zero_slots_out, int32_t* block_tables,
+                                    int32_t* num_blocks, int32_t* kv_lens, const int32_t* seq_lens,
+                                    const int32_t* victim_override, int batch, int max_blocks,
+                                    int method, int cache_budget, int block_size, int topk_blocks,
+                                    int drop_victim_score, int score_layout, float* score_table,
+                                    int32_t* score_counts, const int32_t* score_rows,
+                                    int score_table_width, const void* value_cache,
+                                    int64_t kv_block_stride, int num_kv_heads, int head_size,
+                                    const float* new_scores, int dtype, void* stream) {
+  using namespace pe;
+  PE_REQUIRE(batch <= 0 || (freed_blocks_out && num_blocks && kv_lens && block_tables),
+             PE_ERR_INVALID_ARG, "evict_select_compact_inplace: null pointer");
+  return evict_select_impl(rmv_idx_out, block_tables, zero_slots_out, block_tables, seq_lens,
+                           num_blocks, victim_override, batch, max_blocks, max_blocks, method,
+                           cache_budget, block_size, topk_blocks, drop_victim_score, 0, score_layout,
+                           score_table, score_counts, score_rows, score_table_width, value_cache,
+                           kv_block_stride, num_kv_heads, head_size, new_scores, dtype, stream,
+                           num_blocks, kv_lens, freed_blocks_out);
+}
+
+// ---------------------------------------------------------------------------------------
+// Device-resident decode state: one thread per batch slot appends the step's token.
+}  // extern "C"
+
+namespace pe {
+static __device__ unsigned int state_diag_word;
+
+__global__ void table_state_advance_kernel(
+    int32_t* __restrict__ tables, int32_t* __restrict__ n_blocks, int32_t* __restrict__ kv_lens,
+    int32_t* __restrict__ seq_lens, const int32_t* __restrict__ new_blocks, int batch,
+    int max_blocks, int64_t* __restrict__ slot_mapping_out, int32_t* __restrict__ attn_kv_lens_out,
+    int32_t* __restrict__ last_blocks_out, int rule, int cache_budget, int block_size,
+    int evict_freq, int num_block_merge, int initial_blocks) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  int32_t* row = tables + (int64_t)b * max_blocks;
+  int nb = n_blocks[b];
+  const int kv = kv_lens[b] + 1;   // physical length with this step's token
+  const int L = seq_lens[b] + 1;   // logical length with this step's token
+  const int nblk_new = new_blocks[b];
+  bool bad = false;
+  if (nblk_new >= 0) {
+    if (nb < max_blocks) {
+      row[nb] = nblk_new;
+      nb += 1;
+    } else {
+      bad = true;
+    }
+  }
+  // the token's position must fall into the row's last block (host and device count alike)
+  if (nb <= 0 || (kv - 1) / block_size != nb - 1) bad = true;
+  if (bad) {
+    atomicOr(&state_diag_word, (unsigned)PE_DIAG_TABLE_STATE_MISMATCH);
+    slot_mapping_out[b] = -1;  // the token is not cached rather than written somewhere else
+  } else {
+    slot_mapping_out[b] = (int64_t)row[nb - 1] * block_size + (kv - 1) % block_size;
+  }
+  int attn = kv;
+  if (rule == 1) {  // budget type: one block leaves on a boundary past the budget
+    if (L > cache_budget && L % block_size == 0) attn -= block_size;
+  } else if (rule == 2) {  // percentage type: num_block_merge-1 blocks every evict_freq blocks
+    if (L % (block_size * evict_freq) == 0 && kv > (initial_blocks + num_block_merge) * block_size)
+      attn -= (num_block_merge - 1) * block_size;
+  }
+  n_blocks[b] = nb;
+  kv_lens[b] = kv;
+  seq_lens[b] = L;
+  attn_kv_lens_out[b] = attn;
+  if (last_blocks_out) last_blocks_out[b] = nb > 0 ? row[nb - 1] : 0;
+}
+
+int state_diag_fetch(unsigned int* out, int reset) {
+  void* p = nullptr;
+  hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(state_diag_word));
+  if (e == hipSuccess) e = hipMemcpy(out, p, sizeof(unsigned int), hipMemcpyDeviceToHost);
+  if (e == hipSuccess && reset && *out != 0) e = hipMemset(p, 0, sizeof(unsigned int));
+  if (e != hipSuccess) return fail(PE_ERR_LAUNCH, "state diagnostics: %s", hipGetErrorString(e));
+  return PE_OK;
+}
+}  // namespace pe
+
+extern "C" {
+
+int pe_table_state_advance(int32_t* tables, int32_t* num_blocks, int32_t* kv_lens,
+                           int32_t* seq_lens, const int32_t* new_blocks, int batch, int max_blocks,
+                           int64_t* slot_mapping_out, int32_t* attn_kv_lens_out,
+                           int32_t* last_blocks_out, int evict_rule, int cache_budget,
+                           int block_size, int evict_freq, int num_block_merge, int initial_blocks,
+                           void* stream) {
+  using namespace pe;
+  PE_REQUIRE(batch >= 0, PE_ERR_INVALID_ARG, "negative batch");
+  if (batch == 0) return PE_OK;
+  PE_REQUIRE(tables && num_blocks && kv_lens && seq_lens && new_blocks && slot_mapping_out &&
+                 attn_kv_lens_out,
+             PE_ERR_INVALID_ARG, "table_state_advance: null pointer");
+  PE_REQUIRE(max_blocks > 0 && block_size > 0 && evict_rule >= 0 && evict_rule <= 2,
+             PE_ERR_INVALID_ARG, "table_state_advance: bad sizes");
+  PE_REQUIRE(evict_rule != 2 || (evict_freq > 0 && num_block_merge >= 2), PE_ERR_INVALID_ARG,
+             "table_state_advance: percentage rule needs evict_freq and num_block_merge");
+  hipLaunchKernelGGL(table_state_advance_kernel, dim3((unsigned)((batch + 127) / 128)), dim3(128), 0,
+                     static_cast<hipStream_t>(stream), tables, num_blocks, kv_lens, seq_lens,
+                     new_blocks, batch, max_blocks, slot_mapping_out, attn_kv_lens_out,
+                     last_blocks_out, evict_rule, cache_budget, block_size, evict_freq,
+                     num_block_merge, initial_blocks);
+  return check_launch("table_state_advance");
 }
 
 }  // extern "C"

@@ -35,6 +35,7 @@ inline int elem_size(int dtype) { return dtype == PE_F32 ? 4 : 2; }
 // per-file diagnostic words behind pe_device_diagnostics (defined in paged_decode.hip / evict.hip)
 int decode_diag_fetch(unsigned int* out, int reset);
 int evict_diag_fetch(unsigned int* out, int reset);
+int state_diag_fetch(unsigned int* out, int reset);
 
 // ---- storage types ---------------------------------------------------------------
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;

@@ -80,7 +80,7 @@ def _check_kv_cache_args(kv_cache_dtype: str, k_scale: float, v_scale: float) ->
         raise RuntimeError("paged_evict: k_scale and v_scale must be 1.0")
 
 
-DIAG_DECODE_LEN_CLAMPED, DIAG_SCORE_ROW_FULL = 1, 2
+DIAG_DECODE_LEN_CLAMPED, DIAG_SCORE_ROW_FULL, DIAG_TABLE_STATE_MISMATCH = 1, 2, 4
 
 
 def device_diagnostics(reset: bool = True) -> int:
@@ -104,6 +104,8 @@ def check_device_diagnostics() -> None:
             what.append("a decode launch got a seq_lens entry beyond its block-table row")
         if flags & DIAG_SCORE_ROW_FULL:
             what.append("a block score was dropped because the sequence's score row was full")
+        if flags & DIAG_TABLE_STATE_MISMATCH:
+            what.append("device-resident block tables disagree with the host's counters")
         raise RuntimeError("paged_evict device diagnostics: " + "; ".join(what))
 
 
@@ -525,6 +527,87 @@ def evict_select_compact(block_tables: torch.Tensor, seq_lens: torch.Tensor,
         _p(new_scores), dt if dtype is None else _DT[dtype], _stream(dev)),
         "evict_select_compact")
     return rmv, out_tables, zero
+
+
+def table_state_advance(tables: torch.Tensor, num_blocks: torch.Tensor, kv_lens: torch.Tensor,
+                        seq_lens: torch.Tensor, new_blocks: torch.Tensor, batch: int,
+                        slot_mapping_out: torch.Tensor, attn_kv_lens_out: torch.Tensor,
+                        last_blocks_out: Optional[torch.Tensor], evict_rule: int, cache_budget: int,
+                        block_size: int, evict_freq: int = 0, num_block_merge: int = 2,
+                        initial_blocks: int = 1) -> None:
+    """One decode step's append on device-resident tables (see pe_table_state_advance): rows
+    0..batch-1 of the state arrays are the step's sequences in batch order."""
+    dev = _need_gpu(tables, num_blocks, kv_lens, seq_lens, new_blocks, slot_mapping_out,
+                    attn_kv_lens_out, last_blocks_out)
+    for t in (tables, num_blocks, kv_lens, seq_lens, new_blocks, attn_kv_lens_out):
+        if t.dtype != torch.int32 or not t.is_contiguous():
+            raise RuntimeError("table_state_advance: int32 contiguous tensors expected")
+    if slot_mapping_out.dtype != torch.int64 or not slot_mapping_out.is_contiguous():
+        raise RuntimeError("table_state_advance: slot_mapping_out must be contiguous int64")
+    if tables.dim() != 2 or min(tables.shape[0], num_blocks.numel(), kv_lens.numel(), seq_lens.numel(),
+                                new_blocks.numel(), slot_mapping_out.numel(),
+                                attn_kv_lens_out.numel()) < batch:
+        raise RuntimeError("table_state_advance: state arrays shorter than the batch")
+    lib = _lib.load()
+    _lib.check(lib.pe_table_state_advance(
+        _p(tables), _p(num_blocks), _p(kv_lens), _p(seq_lens), _p(new_blocks), batch, tables.shape[1],
+        _p(slot_mapping_out), _p(attn_kv_lens_out), _p(last_blocks_out), evict_rule, cache_budget,
+        block_size, evict_freq, num_block_merge, initial_blocks, _stream(dev)), "table_state_advance")
+
+
+def evict_select_compact_inplace(block_tables: torch.Tensor, num_blocks: torch.Tensor,
+                                 kv_lens: torch.Tensor, seq_lens: torch.Tensor, batch: int,
+                                 method: str, cache_budget: int, block_size: int,
+                                 topk_blocks: int = -1, *,
+                                 victim_override: Optional[torch.Tensor] = None,
+                                 drop_victim_score: bool = True, score_layout: int = SCORE_CACHE,
+                                 score_table: Optional[torch.Tensor] = None,
+                                 score_counts: Optional[torch.Tensor] = None,
+                                 score_rows: Optional[torch.Tensor] = None,
+                                 value_cache: Optional[torch.Tensor] = None,
+                                 new_scores: Optional[torch.Tensor] = None,
+                                 dtype: Optional[torch.dtype] = None):
+    """pe_evict_select_compact on device-resident tables: rows 0..batch-1 of ``block_tables``
+    lose their victim's column in place, ``num_blocks`` / ``kv_lens`` are updated.  Returns
+    (rmv_idx int32[batch], freed block ids int32[batch] (-1 none), zero_slots int64[batch] or None)."""
+    dev = _need_gpu(block_tables, num_blocks, kv_lens, seq_lens, victim_override, score_table,
+                    score_counts, score_rows, value_cache, new_scores)
+    for t in (block_tables, num_blocks, kv_lens, seq_lens):
+        if t.dtype != torch.int32 or not t.is_contiguous():
+            raise RuntimeError("evict_select_compact_inplace: int32 contiguous tensors expected")
+    if block_tables.dim() != 2 or min(block_tables.shape[0], num_blocks.numel(), kv_lens.numel(),
+                                      seq_lens.numel()) < batch:
+        raise RuntimeError("evict_select_compact_inplace: state arrays shorter than the batch")
+    m = EVICT_METHODS[method]
+    rmv = torch.empty(batch, dtype=torch.int32, device=dev)
+    freed = torch.empty(batch, dtype=torch.int32, device=dev)
+    zero = torch.empty(batch, dtype=torch.int64, device=dev) if m == 1 else None
+    Hkv = D = 0
+    kv_stride = 0
+    dt = _lib.PE_BF16
+    width = 0
+    if m in (2, 3):
+        if victim_override is None or score_table is not None:
+            if score_table is None or score_counts is None or score_rows is None or \
+                    (value_cache is None and new_scores is None):
+                raise RuntimeError("evict_select_compact_inplace: local/global need score_table, "
+                                   "score_counts, score_rows and value_cache (or new_scores)")
+        if value_cache is not None:
+            _, Hkv, D, bs = value_cache.shape
+            if bs != block_size:
+                raise RuntimeError("evict_select_compact_inplace: value_cache block size mismatch")
+            kv_stride = value_cache.stride(0)
+            dt = _dtype_code(value_cache)
+        if score_table is not None:
+            width = score_table.shape[1]
+    lib = _lib.load()
+    _lib.check(lib.pe_evict_select_compact_inplace(
+        _p(rmv), _p(freed), _p(zero), _p(block_tables), _p(num_blocks), _p(kv_lens), _p(seq_lens),
+        _p(victim_override), batch, block_tables.shape[1], m, cache_budget, block_size, topk_blocks,
+        1 if drop_victim_score else 0, score_layout, _p(score_table), _p(score_counts),
+        _p(score_rows), width, _p(value_cache), kv_stride, Hkv, D, _p(new_scores),
+        dt if dtype is None else _DT[dtype], _stream(dev)), "evict_select_compact_inplace")
+    return rmv, freed, zero
 
 
 def merge_blocks_value_l2(key_cache: torch.Tensor, value_cache: torch.Tensor,
