@@ -184,6 +184,11 @@ class Workload:
         self.allreduce = tp_size > 1 and a.oproj_allreduce and tp_group is not None
         self.o_partial_p = self.o_partial_d = None
         if self.allreduce:
+            from vllm_paged_compression_amd import parallel
+            if parallel._one_shot.get(id(tp_group)) is None:
+                # decode-sized partials (<= 1 MiB) go through the one-shot exchange over the
+                # peer-mapped buffers, larger ones through the group's backend (RCCL)
+                parallel.enable_one_shot_all_reduce(tp_group, dev, 1 << 20)
             self.o_partial_p = torch.zeros(Tp, self.hidden, dtype=self.dtype, device=dev)
             self.o_partial_d = torch.zeros(B, self.hidden, dtype=self.dtype, device=dev)
         # decode-kernel timing (HIP events on the launch stream) of one layer

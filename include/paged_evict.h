@@ -4,7 +4,9 @@
  *
  * Conventions
  *  - every pointer named *_dev / documented "device" is a device (HBM) pointer owned
- *    by the caller; the library never allocates or frees memory in these calls;
+ *    by the caller; the library never allocates or frees memory in these calls (the set-up
+ *    calls of the one-shot all-reduce, pe_ar_alloc / pe_ar_free / pe_ar_*_ipc_handle, are the
+ *    exception and say so);
  *  - `stream` is a hipStream_t (NULL = the null stream); all work is enqueued on it
  *    and the call returns without synchronising;
  *  - return value: PE_OK (0) or a PE_ERR_* code; pe_last_error() then returns a
@@ -439,6 +441,42 @@ int pe_rope_reshape_and_cache(void* query, void* key, const void* value, void* k
                               int64_t v_stride, int num_heads, int num_kv_heads, int head_size,
                               int rot_dim, int is_neox, int64_t max_position, int block_size,
                               int64_t num_blocks, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * One-shot all-reduce (sum) for decode-sized messages: the exchange behind the row-parallel
+ * o_proj that follows attention under tensor parallelism
+ * (vllm/model_executor/layers/linear.py:1099-1100).  MI355X counterpart of the reference's
+ * one-stage custom all-reduce (csrc/custom_all_reduce.cu:13-144, csrc/custom_all_reduce.cuh),
+ * which vllm/distributed/parallel_state.py:357-379 tries before NCCL: every rank owns a buffer
+ * all ranks of the node have mapped, publishes its input there, flags its peers, and sums the
+ * N inputs itself (rank order, f32 accumulation: every rank gets the same bits).  Larger
+ * messages belong to RCCL.
+ *   pe_ar_buffer_bytes(max_message_bytes): size of a rank's shared buffer (header + 2 slots).
+ *   pe_ar_alloc / pe_ar_free: the buffer, in uncached device memory, zeroed.  These two and
+ *     the IPC calls are set-up calls: they allocate / map and synchronise the device.
+ *   pe_ar_get_ipc_handle / pe_ar_open_ipc_handle / pe_ar_close_ipc_handle: export the buffer to
+ *     the other ranks (handles are pe_ar_ipc_handle_bytes() opaque bytes, exchanged by the
+ *     caller over any host channel) and map a peer's.
+ *   pe_allreduce_oneshot: out[i] = sum over ranks of in[i], `count` elements of `dtype`
+ *     (message a multiple of 16 bytes and at most the slot size, else PE_ERR_WORKSPACE;
+ *     out may be in).  peer_buffers: HOST array of `world` device pointers, entry r = rank r's
+ *     buffer as mapped in this process (own buffer at index `rank`).  seq: 1, 2, 3, ... - the
+ *     number of this call, the same on every rank (all ranks issue the same calls in the same
+ *     order).  A rank whose peers do not show up within about two seconds stops waiting and
+ *     counts a timeout (pe_ar_timeouts, a synchronising read) instead of hanging the GPU; its
+ *     output is then undefined.
+ * ---------------------------------------------------------------------------------- */
+int64_t pe_ar_buffer_bytes(int64_t max_message_bytes);
+int pe_ar_alloc(void** ptr_out, int64_t bytes);
+int pe_ar_free(void* ptr);
+int pe_ar_ipc_handle_bytes(void);
+int pe_ar_get_ipc_handle(void* ptr, void* handle_out);
+int pe_ar_open_ipc_handle(const void* handle, void** ptr_out);
+int pe_ar_close_ipc_handle(void* ptr);
+int pe_ar_timeouts(const void* own_buffer, unsigned int* count_out);
+int pe_allreduce_oneshot(void* out, const void* in, int64_t count, int dtype,
+                         void* const* peer_buffers, int rank, int world, int64_t buffer_bytes,
+                         unsigned int seq, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Block copy / swap — backend-API obligations (vllm/attention/backends/abstract.py:79-94).

@@ -1,0 +1,131 @@
+"""One-shot all-reduce over HIP-IPC mapped buffers: two ranks (two processes sharing the test
+GPU; the buffers are exchanged as IPC handles exactly as ranks on different GPUs of a node would)
+must produce, bit for bit, the f32-accumulated sum in rank order - for two ranks that is also
+what a gloo all-reduce of the same bf16/fp16/f32 tensors gives.  xGMI bandwidth is not what this
+measures; it pins correctness of the flag protocol, the slot reuse and the dispatch by size."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from vllm_paged_compression_amd import parallel
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        group = dist.group.WORLD
+        comm = parallel.enable_one_shot_all_reduce(group, dev, max_bytes=1 << 20)
+        g = torch.Generator().manual_seed(1000 + rank)
+        checked = 0
+        # decode-sized o_proj partials [B, 8192] and odd small sizes; several calls queued back to
+        # back without a host synchronisation in between exercise the alternating slots
+        cases = [(torch.bfloat16, (1, 8192)), (torch.bfloat16, (64, 8192)), (torch.float16, (7, 4096)),
+                 (torch.float32, (3, 1000)), (torch.bfloat16, (8,)), (torch.bfloat16, (63, 8192))]
+        for rep in range(4):
+            pending = []
+            for dtype, shape in cases:
+                x_cpu = (torch.rand(shape, generator=g) * 2 - 1).to(dtype)
+                x = x_cpu.to(dev)
+                assert comm.should_use(x)
+                seq_before = comm.seq
+                parallel.all_reduce_sum(x, group)          # dispatched to the one-shot path
+                assert comm.seq == seq_before + 1
+                pending.append((x_cpu, x))
+            for x_cpu, x in pending:
+                parts = [torch.empty_like(x_cpu) for _ in range(world)]
+                dist.all_gather(parts, x_cpu)
+                acc = torch.zeros(x_cpu.shape, dtype=torch.float32)
+                for p in parts:                              # rank order, f32 accumulation
+                    acc += p.float()
+                want = acc.to(x_cpu.dtype)
+                got = x.cpu()
+                assert torch.equal(got, want), (rank, x_cpu.dtype, tuple(x_cpu.shape), rep)
+                red = x_cpu.clone()
+                dist.all_reduce(red)                         # gloo's own sum of the same tensors
+                assert torch.equal(got, red)
+                checked += 1
+        # a message beyond the slot goes to the group's backend (gloo here: staged through the host)
+        big = (torch.rand(1 << 20, generator=g)).to(torch.bfloat16)      # 2 MiB
+        xb = big.to(dev)
+        assert not comm.should_use(xb)
+        seq_before = comm.seq
+        parallel.all_reduce_sum(xb, group)
+        assert comm.seq == seq_before
+        red = big.clone()
+        dist.all_reduce(red)
+        assert torch.equal(xb.cpu(), red)
+        # the C entry point refuses what does not fit or is not 16-byte granular
+        from vllm_paged_compression_amd import _lib
+        lib = _lib.load()
+        rc = lib.pe_allreduce_oneshot(xb.data_ptr(), xb.data_ptr(), xb.numel(), _lib.PE_BF16, comm._ptrs,
+                                      rank, world, comm.buffer_bytes, 99, None)
+        assert rc == 4 and b"exceeds" in lib.pe_last_error()
+        assert comm.timeouts() == 0
+        parallel.disable_one_shot_all_reduce(group)
+        q.put((rank, "ok", checked))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, "fail", traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_shot_all_reduce_two_ranks_one_gpu():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=150) for _ in procs)
+    for p in procs:
+        p.join(30)
+    assert all(r[1] == "ok" for r in res), [r[2] for r in res if r[1] != "ok"]
+    assert all(r[2] == 24 for r in res)
+
+
+def test_one_shot_all_reduce_single_rank_is_identity():
+    """world = 1 through the C ABI: out = in (the degenerate sum), no peers to wait for."""
+    import ctypes
+    from vllm_paged_compression_amd import _lib
+    lib = _lib.load()
+    nbytes = lib.pe_ar_buffer_bytes(1 << 16)
+    assert nbytes == 4096 + 2 * (1 << 16)
+    buf = ctypes.c_void_p()
+    _lib.check(lib.pe_ar_alloc(ctypes.byref(buf), nbytes), "ar_alloc")
+    try:
+        ptrs = (ctypes.c_void_p * 1)(buf.value)
+        x = torch.randn(4, 1024, device="cuda").to(torch.bfloat16)
+        y = torch.empty_like(x)
+        for seq in (1, 2, 3):
+            _lib.check(lib.pe_allreduce_oneshot(y.data_ptr(), x.data_ptr(), x.numel(), _lib.PE_BF16, ptrs,
+                                                0, 1, nbytes, seq, torch.cuda.current_stream().cuda_stream),
+                       "allreduce")
+            torch.cuda.synchronize()
+            assert torch.equal(x, y)
+        n = ctypes.c_uint(7)
+        _lib.check(lib.pe_ar_timeouts(buf, ctypes.byref(n)), "ar_timeouts")
+        assert n.value == 0
+        assert lib.pe_allreduce_oneshot(y.data_ptr(), x.data_ptr(), x.numel(), _lib.PE_BF16, ptrs, 0, 1,
+                                        nbytes, 0, None) == 1          # seq starts at 1
+    finally:
+        _lib.check(lib.pe_ar_free(buf), "ar_free")

@@ -73,6 +73,16 @@ SIGNATURES = {
                                           c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
                                           c_int, c_int, c_int, c_int, c_int, c_int64, c_int, c_int64,
                                           c_int, c_void_p]),
+    "pe_ar_buffer_bytes": (c_int64, [c_int64]),
+    "pe_ar_alloc": (c_int, [c_void_p, c_int64]),
+    "pe_ar_free": (c_int, [c_void_p]),
+    "pe_ar_ipc_handle_bytes": (c_int, []),
+    "pe_ar_get_ipc_handle": (c_int, [c_void_p, c_void_p]),
+    "pe_ar_open_ipc_handle": (c_int, [c_void_p, c_void_p]),
+    "pe_ar_close_ipc_handle": (c_int, [c_void_p]),
+    "pe_ar_timeouts": (c_int, [c_void_p, c_void_p]),
+    "pe_allreduce_oneshot": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int, c_int,
+                                     c_int64, ctypes.c_uint, c_void_p]),
     "pe_copy_blocks": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int,
                                c_void_p]),
     "pe_swap_blocks": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),

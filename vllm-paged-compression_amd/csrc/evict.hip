@@ -229,8 +229,14 @@ __global__ __launch_bounds__(SCORE_THREADS) void evict_select_compact_kernel(
   const int w = out_width;
 
   for (int b = b_begin; b < b_end; ++b) {
+    // everything the decision may need is requested up front, so that the dependent chain
+    // (length -> last block id -> value block -> score list) is as short as it can be
     const int seq_len = seq_lens[b];
+    const int nblk_b = num_blocks[b];
+    const int srow_b = score_rows ? score_rows[b] : 0;
     const int32_t* row = block_tables + (int64_t)b * max_blocks;
+    const int last_blk_b = row[max(min(nblk_b, max_blocks) - 1, 0)];
+    const int count_b = score_counts ? score_counts[srow_b] : 0;
     int rmv = -1;
     int64_t zslot = -1;
     const bool over = seq_len > cache_budget;
@@ -245,14 +251,14 @@ __global__ __launch_bounds__(SCORE_THREADS) void evict_select_compact_kernel(
         const int ov = victim_override ? victim_override[b] : -1;
         if (score_table != nullptr) {
           // score the just-filled block and append it to this sequence's list
-          const int srow = score_rows[b];
+          const int srow = srow_b;
           float* list = score_table + (int64_t)srow * score_table_width;
-          int n = score_counts[srow];
+          int n = count_b;
           float s;
           if (new_scores != nullptr) {
             s = new_scores[b];  // scored by the caller (head-sharded caches)
           } else {
-            const int last_blk = row[num_blocks[b] - 1];
+            const int last_blk = last_blk_b;
             s = block_score_wg<T>(value_cache + (int64_t)last_blk * kv_block_stride, score_layout,
                                   num_kv_heads, head_size, block_size, norms, means, stage);
           }

@@ -79,8 +79,117 @@ def broadcast_victims(rmv_idx: torch.Tensor, group: Optional[dist.ProcessGroup] 
     return rmv_idx
 
 
+class OneShotAllReduce:
+    """One-shot all-reduce over peer-mapped buffers for decode-sized messages (the role of the
+    reference's CustomAllreduce, vllm/distributed/device_communicators/custom_all_reduce.py,
+    which ``GroupCoordinator`` tries before NCCL, vllm/distributed/parallel_state.py:357-379).
+
+    Every rank allocates one shared buffer, exports it with HIP IPC, and maps its peers' buffers
+    (the handles travel through ``dist.all_gather_object`` on ``group``, any backend).  Ranks
+    must live on one node; they may even share a device (how the single-GPU tests run it).
+    ``all_reduce`` is in place and must be called by all ranks in the same order."""
+
+    MAX_RANKS = 8
+
+    def __init__(self, group: Optional[dist.ProcessGroup], device, max_bytes: int = 1 << 20):
+        import ctypes
+        from . import _lib
+        self._lib = lib = _lib.load()
+        self._check = _lib.check
+        self.group = group
+        self.device = torch.device(device)
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        if self.world > self.MAX_RANKS:
+            raise ValueError(f"one-shot all-reduce serves up to {self.MAX_RANKS} ranks")
+        self.max_bytes = int(max_bytes)
+        self.buffer_bytes = lib.pe_ar_buffer_bytes(self.max_bytes)
+        self.seq = 0
+        self._own = ctypes.c_void_p()
+        self._peers = []
+        with torch.cuda.device(self.device):
+            self._check(lib.pe_ar_alloc(ctypes.byref(self._own), self.buffer_bytes), "ar_alloc")
+            hb = lib.pe_ar_ipc_handle_bytes()
+            handle = ctypes.create_string_buffer(hb)
+            self._check(lib.pe_ar_get_ipc_handle(self._own, handle), "ar_get_ipc_handle")
+            handles = [None] * self.world
+            dist.all_gather_object(handles, handle.raw, group=group)
+            ptrs = (ctypes.c_void_p * self.world)()
+            for r, h in enumerate(handles):
+                if r == self.rank:
+                    ptrs[r] = self._own.value
+                    continue
+                p = ctypes.c_void_p()
+                self._check(lib.pe_ar_open_ipc_handle(ctypes.create_string_buffer(h, hb), ctypes.byref(p)),
+                            "ar_open_ipc_handle")
+                self._peers.append(p)
+                ptrs[r] = p.value
+            self._ptrs = ptrs
+        dist.barrier(group=group)   # every rank has mapped every buffer before the first call
+
+    def should_use(self, x: torch.Tensor) -> bool:
+        """Message small enough for the shared slot, 16-byte granular, contiguous, on our device."""
+        n = x.numel() * x.element_size()
+        return (x.is_cuda and x.device == self.device and x.is_contiguous() and 0 < n <= self.max_bytes
+                and n % 16 == 0 and x.data_ptr() % 16 == 0
+                and x.dtype in (torch.bfloat16, torch.float16, torch.float32))
+
+    def all_reduce(self, x: torch.Tensor) -> torch.Tensor:
+        from . import _lib
+        code = {torch.float32: _lib.PE_F32, torch.float16: _lib.PE_F16, torch.bfloat16: _lib.PE_BF16}[x.dtype]
+        self.seq += 1
+        self._check(self._lib.pe_allreduce_oneshot(
+            x.data_ptr(), x.data_ptr(), x.numel(), code, self._ptrs, self.rank, self.world,
+            self.buffer_bytes, self.seq, torch.cuda.current_stream(self.device).cuda_stream),
+            "allreduce_oneshot")
+        return x
+
+    def timeouts(self) -> int:
+        """Waits that gave up because a peer never arrived (synchronises the device)."""
+        import ctypes
+        n = ctypes.c_uint(0)
+        with torch.cuda.device(self.device):
+            torch.cuda.synchronize()
+            self._check(self._lib.pe_ar_timeouts(self._own, ctypes.byref(n)), "ar_timeouts")
+        return int(n.value)
+
+    def close(self) -> None:
+        if self._own is None:
+            return
+        with torch.cuda.device(self.device):
+            torch.cuda.synchronize()
+            dist.barrier(group=self.group)      # nobody is still reading our buffer
+            for p in self._peers:
+                self._lib.pe_ar_close_ipc_handle(p)
+            self._lib.pe_ar_free(self._own)
+        self._own, self._peers = None, []
+
+
+_one_shot = {}
+
+
+def enable_one_shot_all_reduce(group: Optional[dist.ProcessGroup], device,
+                               max_bytes: int = 1 << 20) -> OneShotAllReduce:
+    """Register a one-shot communicator for ``group``: ``all_reduce_sum`` then serves messages
+    of up to ``max_bytes`` through it and leaves larger ones to the group's backend (RCCL)."""
+    comm = OneShotAllReduce(group, device, max_bytes)
+    _one_shot[id(group) if group is not None else None] = comm
+    return comm
+
+
+def disable_one_shot_all_reduce(group: Optional[dist.ProcessGroup] = None) -> None:
+    comm = _one_shot.pop(id(group) if group is not None else None, None)
+    if comm is not None:
+        comm.close()
+
+
 def all_reduce_sum(x: torch.Tensor, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
-    """In-place sum over the tensor-parallel group (the o_proj partial-output reduction)."""
+    """In-place sum over the tensor-parallel group (the o_proj partial-output reduction).
+    Dispatch order as the reference's (parallel_state.py:357-379): the one-shot communicator
+    first when one is registered for the group and the message fits it, then the group's own
+    backend."""
+    comm = _one_shot.get(id(group) if group is not None else None)
+    if comm is not None and comm.should_use(x):
+        return comm.all_reduce(x)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         if _host_staged(x, group):
             tmp = x.cpu()
