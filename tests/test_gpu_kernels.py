@@ -777,3 +777,41 @@ def test_device_diagnostics_report_clamps(oracle):
     assert ops.device_diagnostics(reset=True) == ops.DIAG_SCORE_ROW_FULL
     assert int(rmv[0]) == 1          # arg-min over [1, n-1) of the stored scores
     ops.check_device_diagnostics()   # clean again
+
+
+def test_decode_workspace_advertised_size_always_suffices(monkeypatch):
+    """pe_paged_decode_workspace_bytes must cover whatever split count the launch picks - with the
+    library's own choice and with every override of the split / wave tunables."""
+    from vllm_paged_compression_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(3)
+    Hq, Hkv, D = 8, 2, 128
+    nb = 64
+    kc = torch.rand(nb, Hkv, D // 8, 16, 8, generator=g).to(torch.bfloat16).cuda()
+    vc = torch.rand(nb, Hkv, D, 16, generator=g).to(torch.bfloat16).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    checked = 0
+    for forced in (None, "1", "2", "7", "64"):
+        for waves in (None, "8", "16"):
+            for env, val in (("PE_DECODE_SPLITS", forced), ("PE_DECODE_WAVES", waves)):
+                if val is None:
+                    monkeypatch.delenv(env, raising=False)
+                else:
+                    monkeypatch.setenv(env, val)
+            for S in (1, 3, 40):
+                for kv in (1, 31, 64, 129, 300, 776, 1000, 2055, 4104, 9000):
+                    M = (kv + 15) // 16
+                    q = torch.rand(S, Hq, D, generator=g).to(torch.bfloat16).cuda()
+                    bt = torch.randint(0, nb, (S, M), generator=g, dtype=torch.int32).cuda()
+                    lens = torch.full((S,), kv, dtype=torch.int32).cuda()
+                    out = torch.empty_like(q)
+                    need = lib.pe_paged_decode_workspace_bytes(S, Hq, Hkv, D, 16, kv)
+                    ws = torch.empty(max(need, 1), dtype=torch.uint8, device="cuda")
+                    rc = lib.pe_paged_decode(out.data_ptr(), q.data_ptr(), kc.data_ptr(), vc.data_ptr(),
+                                             bt.data_ptr(), lens.data_ptr(), None, S, Hq, Hkv, D, 16, M,
+                                             q.stride(0), kc.stride(0), kc.stride(1), D ** -0.5, kv,
+                                             _lib.PE_BF16, ws.data_ptr() if need else None, need, st)
+                    assert rc == 0, (forced, waves, S, kv, need, lib.pe_last_error())
+                    checked += 1
+    torch.cuda.synchronize()
+    assert checked == 5 * 3 * 3 * 10
