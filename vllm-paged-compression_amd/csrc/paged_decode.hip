@@ -616,6 +616,9 @@ static int decode_impl(void* out, const void* query, const void* key_cache, cons
     dim3 grid((unsigned)splits, (unsigned)num_kv_heads, (unsigned)num_seqs);
     const size_t lds = merge_lds_bytes(waves, num_heads / num_kv_heads, head_size);
 #define PE_LAUNCH_DEC_W(T, HS, W)                                                                \
+  if (lds > 64 * 1024)                                                                           \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&paged_decode_mfma_kernel<T, HS, W>), \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
   hipLaunchKernelGGL((paged_decode_mfma_kernel<T, HS, W>), grid, dim3(W * 64), lds, st, (T*)out, \
                      ws, (const T*)query, (const T*)key_cache, (const T*)value_cache,            \
                      block_tables, seq_lens, alibi_slopes, num_heads, num_kv_heads,              \
@@ -624,9 +627,13 @@ static int decode_impl(void* out, const void* query, const void* key_cache, cons
                      new_v_stride, num_slots, (T*)key_cache, (T*)value_cache)
 #define PE_LAUNCH_DEC(T, HS)                               \
   do {                                                     \
-    if (waves == 16) PE_LAUNCH_DEC_W(T, HS, 16);           \
-    else if (waves == 8) PE_LAUNCH_DEC_W(T, HS, 8);        \
-    else PE_LAUNCH_DEC_W(T, HS, DEC_WAVES);                \
+    if (waves == 16) {                                     \
+      PE_LAUNCH_DEC_W(T, HS, 16);                          \
+    } else if (waves == 8) {                               \
+      PE_LAUNCH_DEC_W(T, HS, 8);                           \
+    } else {                                               \
+      PE_LAUNCH_DEC_W(T, HS, DEC_WAVES);                   \
+    }                                                      \
   } while (0)
     PE_DISPATCH_16(dtype, T, {
       if (head_size == 64) PE_LAUNCH_DEC(T, 64);
