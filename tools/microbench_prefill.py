@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--hkv", type=int, default=8)
     ap.add_argument("--d", type=int, default=128)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--dump", default=None, help="save the output tensor here (A/B comparisons)")
     ap.add_argument("--lib", default=None, help="alternative build of the library (timing experiments)")
     a = ap.parse_args()
     if a.lib:
@@ -44,7 +45,10 @@ def main():
     us = st.elapsed_time(en) * 1e3 / a.iters
     pairs = sum(min(i + 1, a.lkv) for i in range(a.lq))
     flops = 4.0 * a.batch * a.hq * a.d * pairs
-    print(f"prefill B={a.batch} Lq={a.lq} Lkv={a.lkv}: {us:.1f} us, {flops / us / 1e6:.1f} TFLOP/s", flush=True)
+    if a.dump:
+        torch.save(out.cpu(), a.dump)
+    chk = out.view(torch.int16).to(torch.int64).sum().item()   # bit-level checksum for A/B runs
+    print(f"prefill B={a.batch} Lq={a.lq} Lkv={a.lkv}: {us:.1f} us, {flops / us / 1e6:.1f} TFLOP/s, checksum {chk}", flush=True)
 
 
 if __name__ == "__main__":
