@@ -815,3 +815,61 @@ def test_decode_workspace_advertised_size_always_suffices(monkeypatch):
                     checked += 1
     torch.cuda.synchronize()
     assert checked == 5 * 3 * 3 * 10
+
+
+@pytest.mark.parametrize("method,topk,drop", [("streamingLLM", -1, True), ("streamingLLM-1", -1, True),
+                                             ("global", -1, True), ("global", -1, False),
+                                             ("local", 5, True), ("local", 3, False)])
+@pytest.mark.parametrize("inplace", [False, True])
+def test_evict_select_kernels_agree(ops, method, topk, drop, inplace, monkeypatch):
+    """The register-resident form of the decision kernel and the general one (PE_EVICT_FAST=0)
+    leave the same bits everywhere: victims, tables, score lists and counts, zeroed slots, freed
+    block ids, block counts and lengths - on rows that evict, rows that do not, full score rows,
+    host-chosen victims and tables near the width limit of the fast form."""
+    g = torch.Generator().manual_seed(hash((method, topk, drop, inplace)) % (1 << 30))
+    bs, Hkv, D = 16, 4, 64
+    for B, M, budget in [(7, 40, 320), (3, 300, 2048), (5, 2048, 4096), (4, 2100, 4096)]:
+        nb = 64
+        vc = (torch.rand(nb, Hkv, D, bs, generator=g) - 0.5).to(torch.bfloat16).cuda()
+        nblk = torch.randint(budget // bs, min(M, budget // bs + 30) + 1, (B,), generator=g, dtype=torch.int32)
+        nblk = torch.clamp(nblk, max=M)
+        # half the rows sit on a block boundary above the budget (they evict), the others do not
+        seq = nblk * bs - torch.tensor([0 if i % 2 == 0 else 5 for i in range(B)], dtype=torch.int32)
+        tables = torch.randint(0, nb, (B, M), generator=g, dtype=torch.int32)
+        width = M + 2 if M < 2050 else M
+        scores = torch.rand(B + 2, width, generator=g).to(torch.bfloat16).float()
+        counts = torch.zeros(B + 2, dtype=torch.int32)
+        rows = torch.randperm(B + 2, generator=g)[:B].to(torch.int32)
+        for i in range(B):
+            c = int(nblk[i]) - 1
+            counts[int(rows[i])] = width if i == 2 else c     # row 2: the score row is already full
+        ov = None
+        if method == "global" and not drop:
+            ov = torch.full((B,), -1, dtype=torch.int32)
+            ov[0] = 3
+        results = []
+        for fast in ("1", "0"):
+            monkeypatch.setenv("PE_EVICT_FAST", fast)
+            st, ct = scores.clone().cuda(), counts.clone().cuda()
+            kw = dict(victim_override=None if ov is None else ov.cuda(), drop_victim_score=drop,
+                      score_table=st if method in ("local", "global") else None,
+                      score_counts=ct if method in ("local", "global") else None,
+                      score_rows=rows.cuda() if method in ("local", "global") else None,
+                      value_cache=vc if method in ("local", "global") else None)
+            if inplace:
+                tb, nbk, kvl = tables.clone().cuda(), nblk.clone().cuda(), (seq.clone() - 1).cuda()
+                rmv, freed, zero = ops.evict_select_compact_inplace(tb, nbk, kvl, seq.cuda(), B, method,
+                                                                    budget, bs, topk, **kw)
+                out = [rmv, freed, zero, tb, nbk, kvl, st, ct]
+            else:
+                rmv, tabs, zero = ops.evict_select_compact(tables.cuda(), seq.cuda(), nblk.cuda(), method,
+                                                           budget, bs, topk, out_width=M, **kw)
+                out = [rmv, tabs, zero, st, ct]
+            torch.cuda.synchronize()
+            ops.device_diagnostics(reset=True)    # the full score row of row 2 is reported, on purpose
+            results.append([None if t is None else t.cpu() for t in out])
+        for a, b in zip(*results):
+            assert (a is None) == (b is None)
+            if a is not None:
+                assert torch.equal(a, b), (method, B, M)
+        assert (results[0][0] >= 0).any() or method == "streamingLLM-1"

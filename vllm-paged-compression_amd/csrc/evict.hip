@@ -6,13 +6,15 @@
 //                             compaction (+ streamingLLM-1 zero-slot ids), one launch/step
 // Integer / small-FP work: one 64-lane wave per block or per sequence; the byte traffic is
 // one 32 KiB value block per scored block plus the block tables.
+#include <cstdlib>
+
 #include "pe_common.h"
 
 namespace pe {
 
 constexpr int SCORE_MAX_PAIRS = 64 * 64;  // block_size * num_kv_heads held in LDS
 constexpr int SCORE_THREADS = 256;         // workgroup of the scoring kernels
-constexpr int SCORE_STAGE_BYTES = 32 * 1024;  // LDS staging area for paged value slabs
+constexpr int SCORE_STAGE_BYTES = 40 * 1024;  // LDS staging area for paged value slabs (8 padded 128 x 16 slabs of 16-bit values in one pass)
 
 // Set when a sequence's score row is full and a new score could not be appended (the caller
 // sized the table too narrow); read back through pe_device_diagnostics.
@@ -73,7 +75,20 @@ __device__ void block_pair_norms(const T* __restrict__ base, int layout, int num
           const int hh = p / block_size, t = p % block_size;
           const T* v = stage + hh * lds_slab + t;
           float ss = 0.f;
-          for (int d = 0; d < head_size; ++d) {
+          // eight LDS reads in flight, then their squares added in ascending d: the additions
+          // form one dependent chain either way, the read latency is paid once per eight
+          int d = 0;
+          for (; d + 8 <= head_size; d += 8) {
+            T x8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x8[e] = v[(d + e) * block_size];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float x = to_f32(x8[e]);
+              ss += x * x;
+            }
+          }
+          for (; d < head_size; ++d) {
             const float x = to_f32(v[d * block_size]);
             ss += x * x;
           }
@@ -135,12 +150,28 @@ __device__ float block_score_wg(const T* __restrict__ base, int layout, int num_
   block_pair_norms<T>(base, layout, num_kv_heads, head_size, block_size, norms, stage);
   for (int t = threadIdx.x; t < block_size; t += blockDim.x) {
     float hs = 0.f;
-    for (int h = 0; h < num_kv_heads; ++h) hs += norms[t * num_kv_heads + h];
+    int h = 0;
+    for (; h + 4 <= num_kv_heads; h += 4) {  // reads first, sums in ascending h
+      float x4[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x4[e] = norms[t * num_kv_heads + h + e];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) hs += x4[e];
+    }
+    for (; h < num_kv_heads; ++h) hs += norms[t * num_kv_heads + h];
     means[t] = round_to<T>(hs / (float)num_kv_heads);
   }
   __syncthreads();
   float total = 0.f;
-  for (int t = 0; t < block_size; ++t) total += means[t];
+  int t = 0;
+  for (; t + 8 <= block_size; t += 8) {  // reads first, sums in ascending t
+    float x8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x8[e] = means[t + e];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) total += x8[e];
+  }
+  for (; t < block_size; ++t) total += means[t];
   __syncthreads();  // norms/means may be reused by the caller's next block
   return round_to<T>(total);
 }
@@ -371,6 +402,190 @@ __global__ __launch_bounds__(SCORE_THREADS) void evict_select_compact_kernel(
   }
 }
 
+// The same decision for the ordinary case (one workgroup per sequence, no reference-compatible
+// in-loop slice) with the memory round trips taken out of the dependent chain: the table row and
+// the lengths are requested together when the kernel starts, the score list and its count
+// together with the value block, every thread keeps the entries it loaded in registers, and
+// both shifts (score list, table row) are written from those registers - an entry is never read
+// again after something was written.  FAST_SLOTS entries per thread bound the row widths
+// this form takes; wider tables go through evict_select_compact_kernel.
+constexpr int FAST_SLOTS = 8;
+template <typename T>
+__global__ __launch_bounds__(SCORE_THREADS) void evict_select_fast_kernel(
+    int32_t* __restrict__ rmv_idx_out, int32_t* out_tables, int64_t* __restrict__ zero_slots_out,
+    const int32_t* block_tables, const int32_t* __restrict__ seq_lens, const int32_t* num_blocks,
+    const int32_t* __restrict__ victim_override, int max_blocks, int out_width, int method,
+    int cache_budget, int block_size, int topk_blocks, int drop_victim_score, int score_layout,
+    float* score_table, int32_t* score_counts, const int32_t* __restrict__ score_rows,
+    int score_table_width, const T* __restrict__ value_cache, int64_t kv_block_stride,
+    int num_kv_heads, int head_size, const float* __restrict__ new_scores, int32_t* n_blocks_io,
+    int32_t* kv_lens_io, int32_t* __restrict__ freed_out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* norms = reinterpret_cast<float*>(smem);
+  float* means = norms + block_size * num_kv_heads;
+  char* stage = score_stage_ptr(norms, num_kv_heads, block_size);
+  __shared__ int sh_last;
+  __shared__ float red_v[SCORE_THREADS / 64];
+  __shared__ int red_i[SCORE_THREADS / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x;
+
+  // ---- first round trip: lengths, row ------------------------------------------------------
+  const int seq_len = seq_lens[b];
+  const int nblk = num_blocks[b];
+  const int srow = score_rows ? score_rows[b] : 0;
+  const int ov = victim_override ? victim_override[b] : -1;
+  const int32_t* row = block_tables + (int64_t)b * max_blocks;
+  const int row1 = row[1];
+  int32_t my_row[FAST_SLOTS];
+#pragma unroll
+  for (int k = 0; k < FAST_SLOTS; ++k) {
+    const int j = tid + k * SCORE_THREADS;
+    my_row[k] = j < max_blocks ? row[j] : 0;
+  }
+
+  int rmv = -1;
+  int64_t zslot = -1;
+  const bool over = seq_len > cache_budget;
+  const bool boundary = (seq_len % block_size) == 0;
+  if (over && !boundary && method == PE_EVICT_STREAMING_1)
+    zslot = (int64_t)row1 * block_size + (seq_len % block_size) - 1;
+  if (over && boundary && method != PE_EVICT_INVERSE_KEY_L2) {
+    if (method == PE_EVICT_STREAMING || method == PE_EVICT_STREAMING_1) {
+      rmv = 1;
+    } else if (score_table == nullptr) {
+      rmv = ov;  // host-chosen victim (random mode) without score bookkeeping
+    } else {
+      // ---- second round trip: score list and count, value block ----------------------------
+      float* list = score_table + (int64_t)srow * score_table_width;
+      const int count = score_counts[srow];
+      float my_list[FAST_SLOTS];
+#pragma unroll
+      for (int k = 0; k < FAST_SLOTS; ++k) {
+        const int i = tid + k * SCORE_THREADS;
+        my_list[k] = i < score_table_width ? list[i] : 0.f;
+      }
+      float s;
+      if (new_scores != nullptr) {
+        s = new_scores[b];  // scored by the caller (head-sharded caches)
+      } else {
+        const int idx_last = max(min(nblk, max_blocks) - 1, 0);
+#pragma unroll
+        for (int k = 0; k < FAST_SLOTS; ++k)
+          if (tid + k * SCORE_THREADS == idx_last) sh_last = my_row[k];
+        __syncthreads();
+        s = block_score_wg<T>(value_cache + (int64_t)sh_last * kv_block_stride, score_layout,
+                              num_kv_heads, head_size, block_size, norms, means, stage);
+      }
+      int n = count, n_new = -1;
+      if (n < score_table_width) {
+        n_new = n;
+        n += 1;
+      } else if (tid == 0) {
+        atomicOr(&evict_diag_word, (unsigned)PE_DIAG_SCORE_ROW_FULL);
+      }
+      const int start = 1;
+      int end = (method == PE_EVICT_LOCAL) ? 1 + topk_blocks : n - 1;
+      if (end > n) end = n;
+      int best = start;
+      if (ov >= 0) {
+        best = ov;
+      } else {
+        // first arg-min over [start, end): strict '<' keeps the earliest minimum
+        float bv = 0.f;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int k = 0; k < FAST_SLOTS; ++k) {
+          const int i = tid + k * SCORE_THREADS;
+          if (i >= start && i < end) {
+            const float v = (i == n_new) ? s : my_list[k];
+            if (bi == 0x7fffffff || v < bv) {  // a thread's own entries come in ascending i
+              bv = v;
+              bi = i;
+            }
+          }
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+          const float ov2 = __shfl_xor(bv, m);
+          const int oi = __shfl_xor(bi, m);
+          if (oi != 0x7fffffff && (bi == 0x7fffffff || ov2 < bv || (ov2 == bv && oi < bi))) {
+            bv = ov2;
+            bi = oi;
+          }
+        }
+        if (lane == 0) {
+          red_v[wave] = bv;
+          red_i[wave] = bi;
+        }
+        __syncthreads();
+        bv = red_v[0];
+        bi = red_i[0];
+#pragma unroll
+        for (int w2 = 1; w2 < SCORE_THREADS / 64; ++w2) {
+          const float ov2 = red_v[w2];
+          const int oi = red_i[w2];
+          if (oi != 0x7fffffff && (bi == 0x7fffffff || ov2 < bv || (ov2 == bv && oi < bi))) {
+            bv = ov2;
+            bi = oi;
+          }
+        }
+        if (bi != 0x7fffffff) best = bi;
+      }
+      rmv = best;
+      if (drop_victim_score && best < n) {
+        // delete the victim's entry: every entry behind it moves one place to the front
+#pragma unroll
+        for (int k = 0; k < FAST_SLOTS; ++k) {
+          const int i = tid + k * SCORE_THREADS;
+          if (i > best && i < n) list[i - 1] = (i == n_new) ? s : my_list[k];
+        }
+        n -= 1;
+      }
+      if (tid == 0) {
+        if (n_new >= 0) list[n_new] = s;  // the shift above never writes this slot
+        score_counts[srow] = n;
+      }
+    }
+  }
+  if (tid == 0) {
+    rmv_idx_out[b] = rmv;
+    if (zero_slots_out) zero_slots_out[b] = zslot;
+  }
+  __syncthreads();  // every wave's row loads have completed before the row is written
+  if (n_blocks_io != nullptr) {
+    int32_t* r = out_tables + (int64_t)b * max_blocks;  // == row, writable
+    const int n = min(nblk, max_blocks);
+    if (rmv >= 0 && rmv < n) {
+#pragma unroll
+      for (int k = 0; k < FAST_SLOTS; ++k) {
+        const int j = tid + k * SCORE_THREADS;
+        if (j == rmv) freed_out[b] = my_row[k];
+        if (j > rmv && j < n) r[j - 1] = my_row[k];
+      }
+      if (tid == 0) {
+        r[n - 1] = 0;
+        n_blocks_io[b] = nblk - 1;
+        kv_lens_io[b] -= block_size;
+      }
+    } else if (tid == 0) {
+      freed_out[b] = -1;
+    }
+  } else if (out_tables != nullptr && out_width > 0) {
+    int32_t* o = out_tables + (int64_t)b * out_width;
+#pragma unroll
+    for (int k = 0; k < FAST_SLOTS; ++k) {
+      const int j = tid + k * SCORE_THREADS;
+      if (j < max_blocks && j != rmv) {
+        const int dst = (rmv >= 0 && j > rmv) ? j - 1 : j;
+        if (dst < out_width) o[dst] = my_row[k];
+      }
+    }
+    // the column a removal frees at the end of a full-width output
+    if (tid == 0 && rmv >= 0 && rmv < max_blocks && out_width == max_blocks) o[max_blocks - 1] = 0;
+  }
+}
+
 // this file's diagnostic word (see pe_device_diagnostics)
 int evict_diag_fetch(unsigned int* out, int reset) {
   void* p = nullptr;
@@ -488,6 +703,23 @@ static int evict_select_impl(int32_t* rmv_idx_out, int32_t* out_tables, int64_t*
         lds = score_lds_bytes(score_layout, num_kv_heads, head_size, block_size, elem_size(dtype));
       }
     }
+  }
+  // PE_EVICT_FAST=0 sends every call through the general kernel (differential tests)
+  const char* fast_env = getenv("PE_EVICT_FAST");
+  const bool fast_ok = fast_env == nullptr || atoi(fast_env) != 0;
+  if (fast_ok && !compat_q1 && max_blocks <= FAST_SLOTS * SCORE_THREADS &&
+      score_table_width <= FAST_SLOTS * SCORE_THREADS) {
+    PE_DISPATCH_ALL(dtype, T,
+                    hipLaunchKernelGGL(evict_select_fast_kernel<T>, dim3((unsigned)batch),
+                                       dim3(SCORE_THREADS), lds, static_cast<hipStream_t>(stream),
+                                       rmv_idx_out, out_tables, zero_slots_out, block_tables, seq_lens,
+                                       num_blocks, victim_override, max_blocks, out_width, method,
+                                       cache_budget, block_size, topk_blocks, drop_victim_score,
+                                       score_layout, score_table, score_counts, score_rows,
+                                       score_table_width, (const T*)value_cache, kv_block_stride,
+                                       num_kv_heads, head_size, new_scores, n_blocks_io, kv_lens_io,
+                                       freed_out));
+    return check_launch("evict_select_compact");
   }
   const unsigned grid = compat_q1 ? 1u : (unsigned)batch;
   PE_DISPATCH_ALL(dtype, T,
