@@ -1,4 +1,5 @@
 // LDS read-rate microbenchmark: bytes per clock per CU for the read instructions the prefill kernel uses.
+// Build and run:  hipcc --offload-arch=gfx950 -O3 -o lds_read_rate lds_read_rate.hip && ./lds_read_rate
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>

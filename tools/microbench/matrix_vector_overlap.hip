@@ -1,4 +1,5 @@
 // How much do the matrix pipe and the vector pipe of a SIMD overlap?  One workgroup on one CU.
+// Build and run:  hipcc --offload-arch=gfx950 -O3 -o matrix_vector_overlap matrix_vector_overlap.hip && ./matrix_vector_overlap
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
