@@ -69,7 +69,7 @@ __global__ __launch_bounds__(AR_THREADS) void allreduce_oneshot_kernel(
   __threadfence_system();
   __syncthreads();
   // 2. raise flag[b][rank] in every rank's buffer (own included), 3. wait for all of them here
-  if (threadIdx.x < world) {
+  if ((int)threadIdx.x < world) {
     uint32_t* theirs = reinterpret_cast<uint32_t*>(peers.buf[threadIdx.x]) + b * AR_MAX_RANKS + rank;
     __hip_atomic_store(theirs, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     uint32_t* here = reinterpret_cast<uint32_t*>(peers.buf[rank]) + b * AR_MAX_RANKS + threadIdx.x;

@@ -46,8 +46,6 @@ namespace pe {
 #define PE_NOALLOC_SCRATCH_BYTES (8 << 20)
 #endif
 constexpr int DEC_WAVES = PE_DEC_WAVES;
-constexpr int DEC_THREADS = DEC_WAVES * 64;
-constexpr int DEC_MAX_WAVES = 16;  // widest workgroup (one per CU, four waves per SIMD)
 constexpr float NEG_BIG = -1.0e30f;
 
 // Set when a sequence length exceeds what its block-table row addresses and the kernel clamps
