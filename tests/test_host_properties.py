@@ -11,7 +11,9 @@ from vllm_paged_compression_amd.block_table import EvictBlockSpaceManager, Evict
 from vllm_paged_compression_amd.config import PagedEvictConfig
 
 BLOCK_SIZES = (8, 16, 32)
-COMMON = dict(deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+# derandomize: the same examples on every run (a suite that must stay green draws no fresh cases)
+COMMON = dict(deadline=None, derandomize=True, database=None,
+              suppress_health_check=[HealthCheck.function_scoped_fixture])
 
 
 def _cfg(method, budget, topk=3, disable_prefill=True):
