@@ -51,12 +51,25 @@ typedef enum {
   PE_EVICT_INVERSE_KEY_L2 = 4 /* "inverse_key_l2" */
 } pe_evict_method;
 
-/* value layouts accepted by pe_block_score_value_l2 */
+/* score formula of "local" / "global": KVCachePruner.sub_evict_method
+ * (kvcache_prunner.py:13,29-66; HEAD hard-wires "value_l2").  Carried in bits 8..15 of the
+ * `method` argument of pe_prompt_token_select: method | (formula << PE_SCORE_FORMULA_SHIFT). */
+typedef enum {
+  PE_FORMULA_VALUE_L2 = 0,             /* ||V||                        */
+  PE_FORMULA_KEY_L2 = 1,               /* ||K||                        */
+  PE_FORMULA_VALUE_L2_PLUS_KEY_L2 = 2, /* ||V|| + ||K||                */
+  PE_FORMULA_INVERSE_KEY_L2 = 3        /* 1 / (||K|| + 1e-8)           */
+} pe_score_formula;
+#define PE_SCORE_FORMULA_SHIFT 8
+
+/* layouts accepted by pe_block_score_value_l2 */
 typedef enum {
   PE_SCORE_TOKEN_MAJOR = 0, /* dense [block_size, num_kv_heads, head_size] per block */
   PE_SCORE_CACHE = 1,       /* paged value cache block, logical V[token, head, :]   */
-  PE_SCORE_CACHE_FLAT = 2   /* paged block re-viewed flat as [-1, heads, head_size],
+  PE_SCORE_CACHE_FLAT = 2,  /* paged block re-viewed flat as [-1, heads, head_size],
                                the reference's decode-time view (quirk)             */
+  PE_SCORE_KEY_CACHE = 3    /* paged KEY cache block [heads][head_size/x][block_size][x],
+                               logical K[token, head, :] (x = 16 / element size)     */
 } pe_score_layout;
 
 const char* pe_last_error(void);
@@ -233,8 +246,9 @@ int pe_prompt_keep_index_streaming(int32_t* src_index, const int32_t* cu_q,
                                    const int32_t* cu_kept, int num_seqs, int cache_budget,
                                    int block_size, void* stream);
 
-/* Token-level prompt prune for "local"/"global" (score = ||V||_2) and "inverse_key_l2"
- * (score = 1/(||K||_2+1e-8)) (kvcache_prunner.py:29-49,220-257): per request and per KV
+/* Token-level prompt prune for "local"/"global" (score = ||V||_2, or the pe_score_formula in
+ * bits 8..15 of `method`) and "inverse_key_l2" (score = 1/(||K||_2+1e-8))
+ * (kvcache_prunner.py:29-49,220-257): per request and per KV
  * head drops the n_prune lowest-score middle tokens and writes the per-(token, head)
  * kept-row index src_index[(cu_kept[r]+n)*num_kv_heads + h].  Scores are rounded to the
  * storage type like torch.norm's result; equal scores are dropped lowest token first.
@@ -256,9 +270,11 @@ int pe_prompt_token_select(int32_t* src_index, const void* key, const void* valu
                            int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
- * Per-block value_l2 score.  Replaces KVCachePruner.get_block_score
+ * Per-block L2-norm score.  Replaces KVCachePruner.get_block_score
  * (kvcache_prunner.py:51-56): norm over head_size, mean over heads, sum over the
- * block's tokens, each reduction rounded to the storage type as torch does.
+ * block's tokens, each reduction rounded to the storage type as torch does.  The key-norm
+ * formulas of kvcache_prunner.py:57-66 are the same launch on the key tensor (dense rows, or
+ * PE_SCORE_KEY_CACHE for a paged key block) combined by the caller.
  *   layout PE_SCORE_TOKEN_MAJOR: values = dense [*, num_kv_heads, head_size]; block i
  *     covers rows [block_ids[i]*block_size, +block_size) (block_ids NULL: block i = i)
  *     — the prompt-time call site torch_cuda_sdpa.py:1278-1288;

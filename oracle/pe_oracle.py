@@ -240,13 +240,43 @@ def streaming_keep_indices(q_len: int, budget: int, block_size: int) -> List[int
             + list(range(end_mid, q_len)))
 
 
-def token_scores(keys: torch.Tensor, values: torch.Tensor, method: str) -> torch.Tensor:
-    """KVCachePruner.get_token_score, kvcache_prunner.py:29-49 (sub method value_l2, :13)."""
+def token_scores(keys: torch.Tensor, values: torch.Tensor, method: str,
+                 formula: str = "value_l2") -> torch.Tensor:
+    """KVCachePruner.get_token_score, kvcache_prunner.py:29-49; ``formula`` is the sub method
+    of global/local (:13 sets value_l2; the other arms are :35-43)."""
     if method in ("global", "local"):
-        return torch.norm(values, p=2, dim=-1)
+        if formula == "value_l2":
+            return torch.norm(values, p=2, dim=-1)
+        if formula == "key_l2":
+            return torch.norm(keys, p=2, dim=-1)
+        if formula == "value_l2_plus_key_l2":      # value_l2(keys) + key_l2(values), :26-27
+            return torch.norm(keys, p=2, dim=-1) + torch.norm(values, p=2, dim=-1)
+        if formula == "inverse_key_l2":
+            return torch.div(1, torch.norm(keys, p=2, dim=-1) + 1e-8)
+        raise ValueError(formula)
     if method == "inverse_key_l2":
         return torch.div(1, torch.norm(keys, p=2, dim=-1) + 1e-8)
     raise ValueError(method)
+
+
+def block_score_formula(keys: torch.Tensor, values: torch.Tensor, formula: str) -> torch.Tensor:
+    """KVCachePruner.get_block_score for one [bs, H, D] block, kvcache_prunner.py:51-66: 0-d
+    tensor of the input dtype.  The norm / head-mean / token-sum chain is the C restatement
+    (orc_block_score); the sum and the reciprocal of the key arms are torch's 0-d arithmetic."""
+    bs, H, D = values.shape
+    dt = values.dtype
+
+    def nrm(x):
+        return torch.tensor(block_score(x, bs, H, D, 0), dtype=torch.float32).to(dt)
+    if formula == "value_l2":
+        return nrm(values)
+    if formula == "key_l2":
+        return nrm(keys)
+    if formula == "value_l2_plus_key_l2":
+        return nrm(values) + nrm(keys)
+    if formula == "inverse_key_l2":
+        return 1 / (nrm(keys) + 1e-8)
+    raise ValueError(formula)
 
 
 def topk_keep_mask(scores: torch.Tensor, n_prune: int) -> torch.Tensor:
@@ -264,7 +294,7 @@ def topk_keep_mask(scores: torch.Tensor, n_prune: int) -> torch.Tensor:
 
 
 def prompt_prune(keys: torch.Tensor, values: torch.Tensor, method: str, budget: int,
-                 block_size: int, compat_q2: bool = False):
+                 block_size: int, compat_q2: bool = False, formula: str = "value_l2"):
     """KVCachePruner.prune_prompt, kvcache_prunner.py:69-165.  Returns (keys, values).
 
     compat_q2=False: per-head compaction (kept tokens of head h stay in head h).
@@ -279,7 +309,7 @@ def prompt_prune(keys: torch.Tensor, values: torch.Tensor, method: str, budget: 
     end_first, end_mid, n_prune = prompt_slices(L, budget, block_size)
     mk, mv = keys[end_first:end_mid], values[end_first:end_mid]
     if n_prune > 0:
-        keep = topk_keep_mask(token_scores(mk, mv, method), n_prune)
+        keep = topk_keep_mask(token_scores(mk, mv, method, formula), n_prune)
         if compat_q2:
             pk, pv = mk[keep].view(-1, H, D), mv[keep].view(-1, H, D)
         else:

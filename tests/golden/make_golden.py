@@ -157,6 +157,38 @@ def main():
             case += 1
     np.savez_compressed(os.path.join(HERE, "block_scores.npz"), **out)
 
+    # ---- (iii-b) the other score formulas of global/local (sub_evict_method, :29-66) ------
+    # inputs are stored once; per formula the pruned prompt / the block score
+    out = {}
+    formulas = ["value_l2", "key_l2", "value_l2_plus_key_l2", "inverse_key_l2"]
+    for ti, (L, budget, bs, H, D) in enumerate([(80, 48, 16, 4, 16), (150, 64, 16, 3, 8)]):
+        g = torch.Generator().manual_seed(9000 + ti)
+        k = torch.rand(L, H, D, generator=g) * 2 - 1      # tie-free f32
+        v = torch.rand(L, H, D, generator=g) * 2 - 1
+        out[f"t{ti}_meta"] = np.array([L, budget, bs, H, D])
+        out[f"t{ti}_k"], out[f"t{ti}_v"] = bits(k), bits(v)
+        for fi, formula in enumerate(formulas):
+            pp = kp.KVCachePruner("budget", "global", bs, budget, 1)
+            pp.sub_evict_method = formula
+            pk, pv = pp.prune_prompt(k, v)
+            out[f"t{ti}_f{fi}_pk"], out[f"t{ti}_f{fi}_pv"] = bits(pk), bits(pv)
+    bi = 0
+    for dtype, H, D, bs in [(torch.bfloat16, 8, 128, 16), (torch.float16, 12, 64, 16),
+                            (torch.float32, 4, 64, 16), (torch.bfloat16, 2, 128, 32)]:
+        for seed in (0, 1):
+            g = torch.Generator().manual_seed(9500 + 7 * bi + seed)
+            scale = D ** -0.5
+            k = ((torch.rand(bs, H, D, generator=g) * 2 - 1) * scale * 3).to(dtype)
+            v = ((torch.rand(bs, H, D, generator=g) * 2 - 1) * scale).to(dtype)
+            out[f"b{bi}_k"], out[f"b{bi}_v"] = bits(k), bits(v)
+            out[f"b{bi}_meta"] = np.array([bs, H, D, {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}[dtype]])
+            for fi, formula in enumerate(formulas):
+                p = kp.KVCachePruner("budget", "global", bs, 4 * bs, 1)
+                p.sub_evict_method = formula
+                out[f"b{bi}_f{fi}_score"] = bits(p.get_block_score(k, v, "global").reshape(1))
+            bi += 1
+    np.savez_compressed(os.path.join(HERE, "score_formulas.npz"), **out)
+
     # ---- (iv) BlockL2NormManager bookkeeping ----------------------------------------
     mgr = bm.BlockL2NormManager()
     steps = [

@@ -873,3 +873,55 @@ def test_evict_select_kernels_agree(ops, method, topk, drop, inplace, monkeypatc
             if a is not None:
                 assert torch.equal(a, b), (method, B, M)
         assert (results[0][0] >= 0).any() or method == "streamingLLM-1"
+
+
+def test_score_formulas_golden(ops, oracle):
+    """global/local with the other score formulas (KVCachePruner.sub_evict_method,
+    kvcache_prunner.py:29-66) against the reference's outputs: token-level prune through the
+    kernels, block scores through the pruner (dense rows) and from the paged key / value caches."""
+    from test_oracle_golden import FORMULAS
+    from vllm_paged_compression_amd.pruner import KVCachePruner
+    z = np.load(os.path.join(GOLDEN, "score_formulas.npz"))
+    for t in range(2):
+        L, budget, bs, H, D = [int(v) for v in z[f"t{t}_meta"]]
+        k, v = from_bits(z[f"t{t}_k"], 0), from_bits(z[f"t{t}_v"], 0)
+        n_kept = oracle.pruned_length(L, budget, bs)
+        cu_q, cu_k = _cu([L]).cuda(), _cu([n_kept]).cuda()
+        kd, vd = k.cuda(), v.cuda()
+        for fi, f in enumerate(FORMULAS):
+            idx = ops.prompt_token_select(kd, vd, cu_q, cu_k, n_kept, budget, bs, "global",
+                                          compat_q2=True, formula=f)
+            pk, pv = ops.prompt_prune_gather(kd, vd, idx, mode=2)
+            assert torch.equal(pk.cpu(), from_bits(z[f"t{t}_f{fi}_pk"], 0)), (t, f)
+            assert torch.equal(pv.cpu(), from_bits(z[f"t{t}_f{fi}_pv"], 0)), (t, f)
+            # per-head compaction through the pruner's own API
+            p = KVCachePruner("budget", "global", bs, budget, 1)
+            p.sub_evict_method = f
+            pk, pv = p.prune_prompt(kd, vd)
+            ek, ev = oracle.prompt_prune(k, v, "global", budget, bs, formula=f)
+            assert torch.equal(pk.cpu(), ek) and torch.equal(pv.cpu(), ev), (t, f)
+            assert torch.equal(p.get_token_score(k, v, "global"), oracle.token_scores(k, v, "global", f))
+    for b in range(8):
+        bs, H, D, dt = [int(v) for v in z[f"b{b}_meta"]]
+        k, v = from_bits(z[f"b{b}_k"], dt), from_bits(z[f"b{b}_v"], dt)
+        x = 16 // k.element_size()
+        # the same logical rows in the paged layouts: K [H, D/x, bs, x], V [H, D, bs]
+        kc = k.permute(1, 2, 0).reshape(H, D // x, x, bs).permute(0, 1, 3, 2).contiguous().cuda()
+        vc = v.permute(1, 2, 0).contiguous().cuda()
+        for fi, f in enumerate(FORMULAS):
+            expect = from_bits(z[f"b{b}_f{fi}_score"], dt).float().item()
+            p = KVCachePruner("budget", "global", bs, 4 * bs, 1)
+            p.sub_evict_method = f
+            got = p.get_block_score(k.cuda(), v.cuda(), "global").float().item()
+            ks = ops.block_score_value_l2(kc, None, 1, ops.SCORE_KEY_CACHE, H, D, bs)
+            vs = ops.block_score_value_l2(vc, None, 1, ops.SCORE_CACHE, H, D, bs)
+            got_c = ops.combine_block_scores(f, vs, ks, k.dtype).item()
+            if dt == 0:
+                assert got == pytest.approx(expect, rel=3e-6) and got_c == pytest.approx(expect, rel=3e-6)
+            else:
+                assert got == expect and got_c == expect, (b, f, got, got_c, expect)
+        # head-separable form of the key norms (tensor-parallel scoring) on the paged key block
+        sums = ops.block_token_norm_sums(kc, None, 1, ops.SCORE_KEY_CACHE, H, D, bs)
+        two = ops.block_score_from_token_sums(sums, 1, bs, H, k.dtype).item()
+        one = ops.block_score_value_l2(kc, None, 1, ops.SCORE_KEY_CACHE, H, D, bs).item()
+        assert two == one

@@ -270,3 +270,36 @@ def test_ref_cpu_rope_golden(oracle):
                 assert torch.equal(g3[:, :, rot:], x3[:, :, rot:])
             # and a rotation really happened (positions are mostly non-zero)
             assert not torch.equal(got, x)
+
+
+FORMULAS = ["value_l2", "key_l2", "value_l2_plus_key_l2", "inverse_key_l2"]
+
+
+def test_score_formulas_golden(oracle):
+    """The other score formulas of global/local (KVCachePruner.sub_evict_method,
+    kvcache_prunner.py:29-66), from the reference's own class with the attribute assigned:
+    token-level prune outputs (tie-free f32) and block scores in the storage types."""
+    z = np.load(os.path.join(GOLDEN, "score_formulas.npz"))
+    nt = len([k for k in z.files if k.startswith("t") and k.endswith("_meta")])
+    nb = len([k for k in z.files if k.startswith("b") and k.endswith("_meta")])
+    assert nt == 2 and nb == 8
+    for t in range(nt):
+        L, budget, bs, H, D = [int(v) for v in z[f"t{t}_meta"]]
+        k, v = from_bits(z[f"t{t}_k"], 0), from_bits(z[f"t{t}_v"], 0)
+        outs = []
+        for fi, f in enumerate(FORMULAS):
+            pk, pv = oracle.prompt_prune(k, v, "global", budget, bs, compat_q2=True, formula=f)
+            assert torch.equal(pk, from_bits(z[f"t{t}_f{fi}_pk"], 0)), (t, f)
+            assert torch.equal(pv, from_bits(z[f"t{t}_f{fi}_pv"], 0)), (t, f)
+            outs.append(pk)
+        assert not torch.equal(outs[0], outs[1]) and not torch.equal(outs[1], outs[3])
+    for b in range(nb):
+        bs, H, D, dt = [int(v) for v in z[f"b{b}_meta"]]
+        k, v = from_bits(z[f"b{b}_k"], dt), from_bits(z[f"b{b}_v"], dt)
+        for fi, f in enumerate(FORMULAS):
+            expect = from_bits(z[f"b{b}_f{fi}_score"], dt).float().item()
+            got = oracle.block_score_formula(k, v, f).float().item()
+            if dt == 0:
+                assert got == pytest.approx(expect, rel=3e-6), (b, f)
+            else:
+                assert got == expect, (b, f, got, expect)

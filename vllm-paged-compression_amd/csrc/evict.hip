@@ -111,6 +111,30 @@ __device__ void block_pair_norms(const T* __restrict__ base, int layout, int num
     __syncthreads();
     return;
   }
+  if (layout == PE_SCORE_KEY_CACHE) {
+    // paged key block [H][D/X][bs][X]: the X elements of a 16-byte chunk are consecutive d of one
+    // token, consecutive threads take consecutive tokens (coalesced), d ascends with the chunk
+    for (int p = tid; p < pairs; p += nthr) {
+      const int h = p / block_size, t = p % block_size;
+      const T* k = base + ((int64_t)h * (head_size / X) * block_size + t) * X;
+      float ss = 0.f;
+      for (int c = 0; c < head_size / X; ++c) {
+        union {
+          u32x4 raw;
+          T e[X];
+        } u;
+        u.raw = *reinterpret_cast<const u32x4*>(k + (int64_t)c * block_size * X);
+#pragma unroll
+        for (int e = 0; e < X; ++e) {
+          const float x = to_f32(u.e[e]);
+          ss += x * x;
+        }
+      }
+      norms[t * num_kv_heads + h] = round_to<T>(sqrtf(ss));
+    }
+    __syncthreads();
+    return;
+  }
   for (int p = tid; p < pairs; p += nthr) {
     const T* v = base + (int64_t)p * head_size;  // dense rows (token-major or flat re-view)
     float ss = 0.f;
@@ -607,7 +631,10 @@ int pe_block_score_value_l2(float* scores_out, const void* values, const int32_t
   PE_REQUIRE(n_blocks >= 0, PE_ERR_INVALID_ARG, "negative n_blocks");
   if (n_blocks == 0) return PE_OK;
   PE_REQUIRE(scores_out && values, PE_ERR_INVALID_ARG, "block_score: null pointer");
-  PE_REQUIRE(layout >= 0 && layout <= 2, PE_ERR_INVALID_ARG, "block_score: bad layout %d", layout);
+  PE_REQUIRE(layout >= 0 && layout <= PE_SCORE_KEY_CACHE, PE_ERR_INVALID_ARG, "block_score: bad layout %d",
+             layout);
+  PE_REQUIRE(layout != PE_SCORE_KEY_CACHE || head_size % (16 / elem_size(dtype)) == 0, PE_ERR_UNSUPPORTED,
+             "block_score: key cache rows must be made of 16-byte chunks");
   PE_REQUIRE(num_kv_heads > 0 && head_size > 0 && block_size > 0, PE_ERR_INVALID_ARG,
              "block_score: bad sizes");
   PE_REQUIRE(block_size * num_kv_heads <= SCORE_MAX_PAIRS, PE_ERR_UNSUPPORTED,
@@ -629,8 +656,10 @@ int pe_block_token_norm_sums(float* sums_out, const void* values, const int32_t*
   PE_REQUIRE(n_blocks >= 0, PE_ERR_INVALID_ARG, "negative n_blocks");
   if (n_blocks == 0) return PE_OK;
   PE_REQUIRE(sums_out && values, PE_ERR_INVALID_ARG, "block_token_norm_sums: null pointer");
-  PE_REQUIRE(layout == PE_SCORE_TOKEN_MAJOR || layout == PE_SCORE_CACHE, PE_ERR_INVALID_ARG,
-             "block_token_norm_sums: layout %d is not head-separable", layout);
+  PE_REQUIRE(layout == PE_SCORE_TOKEN_MAJOR || layout == PE_SCORE_CACHE || layout == PE_SCORE_KEY_CACHE,
+             PE_ERR_INVALID_ARG, "block_token_norm_sums: layout %d is not head-separable", layout);
+  PE_REQUIRE(layout != PE_SCORE_KEY_CACHE || head_size % (16 / elem_size(dtype)) == 0, PE_ERR_UNSUPPORTED,
+             "block_token_norm_sums: key cache rows must be made of 16-byte chunks");
   PE_REQUIRE(num_kv_heads > 0 && head_size > 0 && block_size > 0, PE_ERR_INVALID_ARG,
              "block_token_norm_sums: bad sizes");
   PE_REQUIRE(block_size * num_kv_heads <= SCORE_MAX_PAIRS, PE_ERR_UNSUPPORTED,

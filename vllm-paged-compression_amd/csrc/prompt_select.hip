@@ -1,5 +1,5 @@
-// Token-level prompt prune ("local" / "global": score ||V||_2, "inverse_key_l2":
-// 1/(||K||_2 + 1e-8)) on gfx950: per request and per KV head, drop the n_prune lowest-score
+// Token-level prompt prune ("local" / "global": score ||V||_2 or another formula of
+// pe_score_formula, "inverse_key_l2": 1/(||K||_2 + 1e-8)) on gfx950: per request and per KV head, drop the n_prune lowest-score
 // tokens of the middle slice and emit the kept-row index used by the gather kernels.
 //
 // Three small launches per call (prefill-time, cold path):
@@ -27,25 +27,37 @@ __global__ void token_score_kernel(float* __restrict__ scores, const T* __restri
   if (i >= total) return;
   const int64_t t = i / num_heads;
   const int h = (int)(i % num_heads);
-  const bool use_key = method == PE_EVICT_INVERSE_KEY_L2;
-  const T* p = use_key ? key + t * key_stride + (int64_t)h * head_size
-                       : value + t * value_stride + (int64_t)h * head_size;
-  float ss = 0.f;
-  for (int c = 0; c < head_size / X; ++c) {
-    union {
-      u32x4 v;
-      T e[X];
-    } u;
-    u.v = *reinterpret_cast<const u32x4*>(p + c * X);
+  // formula: the method's own (inverse_key_l2), else the one carried in bits 8..15
+  const int formula = (method & 0xff) == PE_EVICT_INVERSE_KEY_L2
+                          ? PE_FORMULA_INVERSE_KEY_L2
+                          : (method >> PE_SCORE_FORMULA_SHIFT) & 0xff;
+  auto row_norm = [&](const T* p) {  // ||row||_2 rounded to the storage type, ascending d
+    float ss = 0.f;
+    for (int c = 0; c < head_size / X; ++c) {
+      union {
+        u32x4 v;
+        T e[X];
+      } u;
+      u.v = *reinterpret_cast<const u32x4*>(p + c * X);
 #pragma unroll
-    for (int e = 0; e < X; ++e) {
-      const float x = to_f32(u.e[e]);
-      ss += x * x;
+      for (int e = 0; e < X; ++e) {
+        const float x = to_f32(u.e[e]);
+        ss += x * x;
+      }
     }
-  }
-  float s = round_to<T>(sqrtf(ss));
-  if (use_key) {
-    s = round_to<T>(s + 1e-8f);
+    return round_to<T>(sqrtf(ss));
+  };
+  const T* kp = key + t * key_stride + (int64_t)h * head_size;
+  const T* vp = value + t * value_stride + (int64_t)h * head_size;
+  float s;
+  if (formula == PE_FORMULA_VALUE_L2) {
+    s = row_norm(vp);
+  } else if (formula == PE_FORMULA_KEY_L2) {
+    s = row_norm(kp);
+  } else if (formula == PE_FORMULA_VALUE_L2_PLUS_KEY_L2) {
+    s = round_to<T>(row_norm(kp) + row_norm(vp));
+  } else {
+    s = round_to<T>(row_norm(kp) + 1e-8f);
     s = round_to<T>(1.0f / s);
   }
   scores[i] = s;
@@ -265,8 +277,14 @@ int pe_prompt_token_select(int32_t* src_index, const void* key, const void* valu
   if (num_seqs == 0) return PE_OK;
   PE_REQUIRE(src_index && key && value && cu_q && cu_kept, PE_ERR_INVALID_ARG,
              "prompt_token_select: null pointer");
-  PE_REQUIRE(method == PE_EVICT_LOCAL || method == PE_EVICT_GLOBAL || method == PE_EVICT_INVERSE_KEY_L2,
-             PE_ERR_INVALID_ARG, "token-level prune is defined for local/global/inverse_key_l2");
+  {
+    const int base = method & 0xff, formula = (method >> PE_SCORE_FORMULA_SHIFT) & 0xff;
+    PE_REQUIRE((base == PE_EVICT_LOCAL || base == PE_EVICT_GLOBAL || base == PE_EVICT_INVERSE_KEY_L2) &&
+                   (method >> 16) == 0,
+               PE_ERR_INVALID_ARG, "token-level prune is defined for local/global/inverse_key_l2");
+    PE_REQUIRE(formula <= PE_FORMULA_INVERSE_KEY_L2, PE_ERR_INVALID_ARG, "unknown score formula %d",
+               formula);
+  }
   PE_REQUIRE(block_size > 0 && (cache_budget >= 3 * block_size || (cache_budget == 0 && tail_blocks >= 1)),
              PE_ERR_INVALID_ARG,
              "cache budget must be at least 3 blocks (kvcache_prunner.py:15), or 0 with tail_blocks >= 1");

@@ -22,7 +22,10 @@ _DT = {torch.float32: _lib.PE_F32, torch.float16: _lib.PE_F16, torch.bfloat16: _
 
 EVICT_METHODS = {"streamingLLM": 0, "streamingLLM-1": 1, "local": 2, "global": 3,
                  "inverse_key_l2": 4}
-SCORE_TOKEN_MAJOR, SCORE_CACHE, SCORE_CACHE_FLAT = 0, 1, 2
+SCORE_TOKEN_MAJOR, SCORE_CACHE, SCORE_CACHE_FLAT, SCORE_KEY_CACHE = 0, 1, 2, 3
+# KVCachePruner.sub_evict_method (kvcache_prunner.py:13,29-66) -> pe_score_formula
+SCORE_FORMULAS = {"value_l2": 0, "key_l2": 1, "value_l2_plus_key_l2": 2, "inverse_key_l2": 3}
+_SCORE_FORMULA_SHIFT = 8
 
 
 def _dtype_code(t: torch.Tensor) -> int:
@@ -377,11 +380,14 @@ def prompt_keep_index_streaming(cu_q: torch.Tensor, cu_kept: torch.Tensor, total
 def prompt_token_select(key: torch.Tensor, value: torch.Tensor, cu_q: torch.Tensor,
                         cu_kept: torch.Tensor, total_kept: int, cache_budget: int,
                         block_size: int, method: str, compat_q2: bool = False,
-                        tail_blocks: int = 1) -> torch.Tensor:
+                        tail_blocks: int = 1, formula: str = "value_l2") -> torch.Tensor:
     """Per-(token, head) kept-row index [total_kept, H_kv] int32 of the token-level prompt prune.
     cache_budget 0: percentage prune type (the last ``tail_blocks`` blocks stay, the pruned count
-    of a prompt is its length minus its kept length)."""
+    of a prompt is its length minus its kept length).  ``formula``: the score of "local" /
+    "global" (SCORE_FORMULAS; "inverse_key_l2" as a method always uses its own)."""
     dev = _need_gpu(key, value, cu_q, cu_kept)
+    if formula not in SCORE_FORMULAS:
+        raise ValueError(f"Unknown score formula: {formula}")
     T, H, D = key.shape
     idx = torch.empty((total_kept, H), dtype=torch.int32, device=dev)
     lib = _lib.load()
@@ -389,7 +395,8 @@ def prompt_token_select(key: torch.Tensor, value: torch.Tensor, cu_q: torch.Tens
     ws = _workspace(dev, need, "select")
     _lib.check(lib.pe_prompt_token_select(
         _p(idx), _p(key), _p(value), _p(cu_q), _p(cu_kept), cu_q.numel() - 1, T, cache_budget,
-        block_size, EVICT_METHODS[method], 1 if compat_q2 else 0, tail_blocks, key.stride(0),
+        block_size, EVICT_METHODS[method] | (SCORE_FORMULAS[formula] << _SCORE_FORMULA_SHIFT),
+        1 if compat_q2 else 0, tail_blocks, key.stride(0),
         value.stride(0),
         H, D, _dtype_code(key), _p(ws), 0 if ws is None else ws.numel(), _stream(dev)),
         "prompt_token_select")
@@ -429,6 +436,22 @@ def block_score_value_l2(values: torch.Tensor, block_ids: Optional[torch.Tensor]
                                            _dtype_code(values), _stream(dev)),
                "block_score_value_l2")
     return out
+
+
+def combine_block_scores(formula: str, value_scores: Optional[torch.Tensor],
+                         key_scores: Optional[torch.Tensor], dtype: torch.dtype) -> torch.Tensor:
+    """Block scores of a score formula from the L2-norm block scores of the value and key tensors
+    (f32 tensors holding storage-type values, as block_score_value_l2 returns them), with the
+    roundings torch applies to 0-d tensors of the storage type (kvcache_prunner.py:51-66)."""
+    if formula == "value_l2":
+        return value_scores
+    if formula == "key_l2":
+        return key_scores
+    if formula == "value_l2_plus_key_l2":
+        return (value_scores.to(dtype) + key_scores.to(dtype)).float()
+    if formula == "inverse_key_l2":
+        return (1 / (key_scores.to(dtype) + 1e-8)).float()
+    raise ValueError(f"Unknown score formula: {formula}")
 
 
 def block_token_norm_sums(values: torch.Tensor, block_ids: Optional[torch.Tensor], n_blocks: int,

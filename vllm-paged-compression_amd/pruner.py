@@ -32,7 +32,9 @@ class KVCachePruner:
         self.evict_method = evict_method
         self.orig_block_size = block_size
         self.cache_budget = cache_budget
-        self.sub_evict_method = "value_l2"   # score used by "global" and "local"
+        # score used by "global" and "local" (kvcache_prunner.py:13 hard-wires "value_l2"; the
+        # other formulas of :29-66 are reached by assigning the attribute, as in the reference)
+        self.sub_evict_method = "value_l2"
         self.initial_blocks = initial_blocks
         self.cross_head_compat = cross_head_compat
         self.evict_frequency = evict_freq
@@ -126,7 +128,8 @@ class KVCachePruner:
         else:
             idx = ops.prompt_token_select(key, value, cu_q, cu_kept, total, self.cache_budget,
                                           self.orig_block_size, self.evict_method,
-                                          compat_q2=self.cross_head_compat)
+                                          compat_q2=self.cross_head_compat,
+                                          formula=self._formula())
         return idx, kept
 
     def _gather(self, key, value, idx):
@@ -161,31 +164,62 @@ class KVCachePruner:
         k, v = self._gather(key, value, idx)
         return k, v, kept
 
+    def _formula(self) -> str:
+        if self.sub_evict_method not in ops.SCORE_FORMULAS:
+            raise ValueError(f"Unknown sub eviction method: {self.sub_evict_method}")
+        return self.sub_evict_method
+
     def get_token_score(self, keys: torch.Tensor, values: torch.Tensor, evict_method: str):
-        """[T, H] scores: ||V||_2 for global/local, 1/(||K||_2+1e-8) for inverse_key_l2."""
+        """[T, H] scores (kvcache_prunner.py:29-49): the sub method's formula for global/local
+        (||V||_2 by default), 1/(||K||_2+1e-8) for inverse_key_l2."""
         if evict_method in ("global", "local"):
-            return torch.norm(values, p=2, dim=-1)
+            f = self._formula()
+            if f == "value_l2":
+                return torch.norm(values, p=2, dim=-1)
+            if f == "key_l2":
+                return torch.norm(keys, p=2, dim=-1)
+            if f == "value_l2_plus_key_l2":
+                return torch.norm(keys, p=2, dim=-1) + torch.norm(values, p=2, dim=-1)
+            return torch.div(1, torch.norm(keys, p=2, dim=-1) + 1e-8)
         if evict_method == "inverse_key_l2":
             return torch.div(1, torch.norm(keys, p=2, dim=-1) + 1e-8)
         raise ValueError(f"Unknown eviction method: {evict_method}")
 
     def get_block_score(self, block_keys: torch.Tensor, block_values: torch.Tensor,
                         evict_method: str) -> torch.Tensor:
-        """value_l2 score of one [block_size, H, D] block (0-d tensor of the input dtype)."""
+        """Score of one [block_size, H, D] block under the sub method (0-d tensor of the input
+        dtype; kvcache_prunner.py:51-66)."""
         assert evict_method in ("global", "local"), \
             "Only global and local eviction methods are supported for block score calculation"
-        bs, H, D = block_values.shape
-        s = ops.block_score_value_l2(block_values.contiguous(), None, 1, ops.SCORE_TOKEN_MAJOR,
-                                     H, D, bs)
+        bs = block_values.shape[0]
+        s = self.get_block_scores_dense(block_values, 1, keys=block_keys, block_size=bs)
         return s[0].to(block_values.dtype)
 
     def get_block_scores_dense(self, values: torch.Tensor, n_blocks: int,
-                               out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Scores of the first n_blocks whole blocks of a dense [T, H, D] value tensor
-        (the prompt-time loop of torch_cuda_sdpa.py:1278-1288 as one launch); f32 [n_blocks]."""
+                               out: Optional[torch.Tensor] = None,
+                               keys: Optional[torch.Tensor] = None,
+                               block_size: Optional[int] = None) -> torch.Tensor:
+        """Scores of the first n_blocks whole blocks of dense [T, H, D] value (and key) tensors
+        (the prompt-time loop of torch_cuda_sdpa.py:1278-1288 as one launch per tensor); f32
+        [n_blocks].  ``keys`` is needed by every formula but value_l2."""
         T, H, D = values.shape
-        return ops.block_score_value_l2(values, None, n_blocks, ops.SCORE_TOKEN_MAJOR, H, D,
-                                        self.orig_block_size, out=out)
+        bs = block_size or self.orig_block_size
+        f = self._formula()
+        if f == "value_l2":
+            return ops.block_score_value_l2(values.contiguous(), None, n_blocks, ops.SCORE_TOKEN_MAJOR,
+                                            H, D, bs, out=out)
+        if keys is None:
+            raise ValueError(f"score formula {f} needs the keys")
+        ks = ops.block_score_value_l2(keys.contiguous(), None, n_blocks, ops.SCORE_TOKEN_MAJOR, H, D, bs)
+        vs = None
+        if f == "value_l2_plus_key_l2":
+            vs = ops.block_score_value_l2(values.contiguous(), None, n_blocks, ops.SCORE_TOKEN_MAJOR,
+                                          H, D, bs)
+        sc = ops.combine_block_scores(f, vs, ks, values.dtype)
+        if out is not None:
+            out.copy_(sc)
+            return out
+        return sc
 
 
 def _cumsum(lens: Sequence[int], device) -> torch.Tensor:
