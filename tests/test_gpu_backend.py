@@ -30,9 +30,14 @@ def _builder(cfg, inter):
     return PagedEvictBackend.make_metadata_builder(ib)
 
 
-@pytest.mark.parametrize("method", ["streamingLLM", "streamingLLM-1", "global", "local"])
+@pytest.mark.parametrize("method,formula", [("streamingLLM", "value_l2"), ("streamingLLM-1", "value_l2"),
+                                            ("global", "value_l2"), ("local", "value_l2"),
+                                            ("global", "key_l2"), ("global", "value_l2_plus_key_l2"),
+                                            ("local", "inverse_key_l2")])
 @pytest.mark.parametrize("disable_evict_prefill", [True, False])
-def test_backend_generation_trace(oracle, method, disable_evict_prefill):
+def test_backend_generation_trace(oracle, method, formula, disable_evict_prefill):
+    """A generation through the backend against a CPU walk of the reference's steps.  ``formula``
+    is the score of global/local (KVCachePruner.sub_evict_method, kvcache_prunner.py:13,29-66)."""
     from vllm_paged_compression_amd.backend import PagedEvictBackend
     from vllm_paged_compression_amd.block_table import EvictBlockSpaceManager, EvictionScheduler
     from vllm_paged_compression_amd.config import CacheConfigView, PagedEvictConfig
@@ -46,6 +51,8 @@ def test_backend_generation_trace(oracle, method, disable_evict_prefill):
     impl_cls = PagedEvictBackend.get_impl_cls()
     impls = [impl_cls(Hq, D, D ** -0.5, Hkv, None, None, "auto", None, None, cache_config=cache_cfg,
                       prefix=f"model.layers.{i}.self_attn.attn") for i in range(L_layers)]
+    for im in impls:
+        im.kv_cache_pruner.sub_evict_method = formula
     shape = PagedEvictBackend.get_kv_cache_shape(nb, BS, Hkv, D)
     kv_gpu = [torch.zeros(shape, dtype=torch.bfloat16, device="cuda") for _ in range(L_layers)]
     x = 8
@@ -89,7 +96,8 @@ def test_backend_generation_trace(oracle, method, disable_evict_prefill):
         k3, v3, q3 = k.view(T, Hkv, D), v.view(T, Hkv, D), q.view(T, Hq, D)
         pk, pv, off = [], [], 0
         for n in lens:
-            a, b = oracle.prompt_prune(k3[off:off + n], v3[off:off + n], method, budget, BS)
+            a, b = oracle.prompt_prune(k3[off:off + n], v3[off:off + n], method, budget, BS,
+                                       formula=formula)
             pk.append(a)
             pv.append(b)
             off += n
@@ -105,7 +113,9 @@ def test_backend_generation_trace(oracle, method, disable_evict_prefill):
         assert torch.equal(kc_g.cpu(), kc_cpu[li]) and torch.equal(vc_g.cpu(), vc_cpu[li])
         if li == 0 and method in ("global", "local"):
             for i, t in enumerate(pv):
-                scores[i] = [oracle.block_score(t[b * BS:(b + 1) * BS].contiguous(), BS, Hkv, D, 0)
+                scores[i] = [oracle.block_score_formula(pk[i][b * BS:(b + 1) * BS].contiguous(),
+                                                        t[b * BS:(b + 1) * BS].contiguous(),
+                                                        formula).float().item()
                              for b in range(t.shape[0] // BS)]
     assert impls[0].get_rmv_block_idx() == {}
 
@@ -144,7 +154,12 @@ def test_backend_generation_trace(oracle, method, disable_evict_prefill):
             rmv = []
             for i, L in enumerate(logical):
                 if oracle.decode_trigger(L, budget, BS):
-                    new = oracle.block_score(vc_cpu[0][tbls[i][-1]], BS, Hkv, D, 1)
+                    blk = tbls[i][-1]        # the just-filled block, back in token-major rows
+                    k_tm = kc_cpu[0][blk].permute(2, 0, 1, 3).reshape(BS, Hkv, D).contiguous()
+                    v_tm = vc_cpu[0][blk].permute(2, 0, 1).contiguous()
+                    new = oracle.block_score_formula(k_tm, v_tm, formula).float().item()
+                    if formula == "value_l2":
+                        assert new == oracle.block_score(vc_cpu[0][blk], BS, Hkv, D, 1)
                     rmv.append(oracle.decode_topk_victim(scores[i], new, method, 3, True))
                 else:
                     rmv.append(-1)

@@ -12,7 +12,8 @@ pytestmark = pytest.mark.gpu
 BS = 16
 
 
-def _generation(method, prompt_len, budget, n_decode, device_tables, B=6, Hq=8, Hkv=2, D=128, layers=2):
+def _generation(method, prompt_len, budget, n_decode, device_tables, B=6, Hq=8, Hkv=2, D=128, layers=2,
+                formula="value_l2"):
     from vllm_paged_compression_amd.backend import PagedEvictBackend
     from vllm_paged_compression_amd.batch_scheduler import BatchEvictionScheduler
     from vllm_paged_compression_amd.config import CacheConfigView, PagedEvictConfig
@@ -25,6 +26,8 @@ def _generation(method, prompt_len, budget, n_decode, device_tables, B=6, Hq=8, 
                                               cache_config=ccfg, prefix=f"model.layers.{i}.self_attn.attn",
                                               max_num_seqs=B, max_blocks_per_seq=per_seq + 2)
              for i in range(layers)]
+    for impl in impls:
+        impl.kv_cache_pruner.sub_evict_method = formula
     kv = [torch.zeros(PagedEvictBackend.get_kv_cache_shape(nb, BS, Hkv, D), dtype=torch.bfloat16, device=dev)
           for _ in range(layers)]
     sched = BatchEvictionScheduler(BS, nb, cfg, max_seqs=B, max_blocks_per_seq=per_seq + 2,
@@ -77,14 +80,17 @@ def _generation(method, prompt_len, budget, n_decode, device_tables, B=6, Hq=8, 
     return victims, outs, tables, [t.cpu() for t in kv], h2d
 
 
-@pytest.mark.parametrize("method", ["streamingLLM", "streamingLLM-1", "global", "local", "inverse_key_l2"])
-def test_device_tables_match_host_tables(method):
+@pytest.mark.parametrize("method,formula", [("streamingLLM", "value_l2"), ("streamingLLM-1", "value_l2"),
+                                            ("global", "value_l2"), ("local", "value_l2"),
+                                            ("inverse_key_l2", "value_l2"), ("global", "key_l2"),
+                                            ("local", "value_l2_plus_key_l2")])
+def test_device_tables_match_host_tables(method, formula):
     import random
     from vllm_paged_compression_amd import ops
     random.seed(1234)
-    a = _generation(method, 150, 128, 40, device_tables=False)
+    a = _generation(method, 150, 128, 40, device_tables=False, formula=formula)
     random.seed(1234)
-    b = _generation(method, 150, 128, 40, device_tables=True)
+    b = _generation(method, 150, 128, 40, device_tables=True, formula=formula)
     assert a[0] == b[0], "victims differ"
     assert a[2] == b[2], "final tables differ"
     for x, y in zip(a[1], b[1]):

@@ -37,7 +37,8 @@ def _inputs(T, g):
 
 def run_trace(rank, world, group, mode="budget"):
     """One generation on this rank's head shard; returns ([victims per step], [output per step
-    and layer, all on the CPU], final block tables).  mode "budget": value_l2 block eviction;
+    and layer, all on the CPU], final block tables).  mode "budget": value_l2 block eviction
+    ("budget:<formula>": the same with another score formula of KVCachePruner.sub_evict_method);
     "percentage": the README-era type with the per-head value_l2 block merge at decode."""
     sys.path.insert(0, ROOT)
     from vllm_paged_compression_amd import parallel
@@ -58,6 +59,9 @@ def run_trace(rank, world, group, mode="budget"):
         sh.num_heads, D, D ** -0.5, sh.num_kv_heads, None, None, "auto", None, None,
         cache_config=ccfg, prefix=f"model.layers.{i}.self_attn.attn", tp_group=group,
         total_num_kv_heads=HKV) for i in range(LAYERS)]
+    if ":" in mode:
+        for impl in impls:
+            impl.kv_cache_pruner.sub_evict_method = mode.split(":", 1)[1]
     shape = PagedEvictBackend.get_kv_cache_shape(nb, BS, sh.num_kv_heads, D)
     kv = [torch.zeros(shape, dtype=torch.bfloat16, device=dev) for _ in range(LAYERS)]
     sched = EvictionScheduler(EvictBlockSpaceManager(BS, nb, cfg, watermark=0.0))
@@ -131,7 +135,7 @@ def _worker(rank, world, port, q, mode="budget"):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["budget", "percentage"])
+@pytest.mark.parametrize("mode", ["budget", "percentage", "budget:value_l2_plus_key_l2"])
 def test_two_rank_value_l2_eviction_matches_single_rank(mode):
     import torch.multiprocessing as mp
     ref_victims, ref_out, ref_tables = run_trace(0, 1, None, mode)

@@ -616,7 +616,7 @@ class PagedEvictImpl(_ImplBase):
                 PagedAttention.write_to_paged_cache(pk, pv, key_cache, value_cache,
                                                     meta.slot_mapping[:pk.shape[0]],
                                                     self.kv_cache_dtype, 1.0, 1.0)
-                self._prompt_block_scores(pv, kept, meta)
+                self._prompt_block_scores(pv, kept, meta, pk)
         else:
             ops.prefill_causal(q, k, v, cu_q, cu_q, max_q, self.scale, out=out[:nt])
             if not is_profile_run:
@@ -627,13 +627,13 @@ class PagedEvictImpl(_ImplBase):
                         self.kv_cache_dtype, 1.0, 1.0, src_index=src_index, src_pairs=pairs)
                     if self._needs_scores():
                         pk, pv = ops.prompt_prune_gather(k, v, src_index, mode=2 if pairs else None)
-                        self._prompt_block_scores(pv, kept, meta)
+                        self._prompt_block_scores(pv, kept, meta, pk)
                 else:
                     PagedAttention.write_to_paged_cache(k, v, key_cache, value_cache,
                                                         meta.slot_mapping[:nt], self.kv_cache_dtype,
                                                         1.0, 1.0)
                     if self.enabled_paged_eviction:
-                        self._prompt_block_scores(v, list(seq_lens), meta)
+                        self._prompt_block_scores(v, list(seq_lens), meta, k)
 
     def _step_keys(self, meta) -> List[Tuple[str, int]]:
         """(request id, sequence id) of every sequence of the step, in batch order."""
@@ -679,7 +679,55 @@ class PagedEvictImpl(_ImplBase):
             self._score_table = DeviceScoreTable(2 * self.max_num_seqs, self.max_blocks_per_seq, device)
         return self._score_table
 
-    def _prompt_block_scores(self, values: torch.Tensor, kept: List[int], meta) -> None:
+    def _score_formula(self) -> str:
+        """Score formula of global/local: the pruner's sub method (kvcache_prunner.py:13,51-66)."""
+        f = getattr(self.kv_cache_pruner, "sub_evict_method", "value_l2")
+        if f not in ops.SCORE_FORMULAS:
+            raise ValueError(f"Unknown sub eviction method: {f}")
+        return f
+
+    def _norm_block_scores(self, tensor: torch.Tensor, ids: torch.Tensor, n: int, layout: int,
+                           block_stride: int) -> torch.Tensor:
+        """L2-norm block scores (norm, head mean, token sum) of n blocks of the key or the value
+        tensor: one launch, or under rank-invariant tensor-parallel scoring the token sums of
+        the local heads, all-reduced, then finished."""
+        bs = self.cache_config.block_size
+        H, D = self.num_kv_heads, self.head_size
+        if self._tp_exact_scores():
+            sums = ops.block_token_norm_sums(tensor, ids, n, layout, H, D, bs, block_stride=block_stride)
+            self._reduce_token_sums(sums)
+            return ops.block_score_from_token_sums(sums, n, bs, self.total_num_kv_heads, tensor.dtype)
+        return ops.block_score_value_l2(tensor, ids, n, layout, H, D, bs, block_stride=block_stride)
+
+    def _formula_block_scores(self, keys: Optional[torch.Tensor], values: torch.Tensor,
+                              ids: torch.Tensor, n: int, key_layout: int, value_layout: int,
+                              block_stride: int) -> torch.Tensor:
+        """Scores of n blocks under the score formula in force (f32 [n])."""
+        f = self._score_formula()
+        vs = ks = None
+        if f in ("value_l2", "value_l2_plus_key_l2"):
+            vs = self._norm_block_scores(values, ids, n, value_layout, block_stride)
+        if f != "value_l2":
+            if keys is None:
+                raise RuntimeError(f"score formula {f} needs the keys")
+            ks = self._norm_block_scores(keys, ids, n, key_layout, block_stride)
+        return ops.combine_block_scores(f, vs, ks, values.dtype)
+
+    def _new_block_scores(self, key_cache: torch.Tensor, value_cache: torch.Tensor,
+                          last_blocks: torch.Tensor, n: int) -> Optional[torch.Tensor]:
+        """Scores of the sequences' just-filled blocks when the decision launch cannot compute
+        them itself (it scores value norms of all KV heads of this rank): rank-invariant
+        tensor-parallel scoring, or a formula with key norms.  None = let the launch do it."""
+        if self._score_formula() == "value_l2" and not self._tp_exact_scores():
+            return None
+        flat = self.compat.score_flat_cache_view
+        return self._formula_block_scores(
+            key_cache, value_cache, last_blocks, n,
+            ops.SCORE_CACHE_FLAT if flat else ops.SCORE_KEY_CACHE,
+            ops.SCORE_CACHE_FLAT if flat else ops.SCORE_CACHE, value_cache.stride(0))
+
+    def _prompt_block_scores(self, values: torch.Tensor, kept: List[int], meta,
+                             keys_dense: Optional[torch.Tensor] = None) -> None:
         """Scores of every whole block of each (pruned) prompt -> the sequence's score row
         (torch_cuda_sdpa.py:1278-1288)."""
         if not self._needs_scores():
@@ -710,15 +758,11 @@ class PagedEvictImpl(_ImplBase):
             n_all = len(offs)
             ids = torch.tensor(offs, dtype=torch.int32, device=dev)
             dst = torch.tensor(idx, dtype=torch.int64, device=dev)
-            if self._tp_exact_scores():
-                sums = ops.block_token_norm_sums(values, ids, n_all, ops.SCORE_TOKEN_MAJOR, H, D, bs,
-                                                 block_stride=values.stride(0))
-                self._reduce_token_sums(sums)
-                sc = ops.block_score_from_token_sums(sums, n_all, bs, self.total_num_kv_heads,
-                                                     values.dtype)
-            else:
-                sc = ops.block_score_value_l2(values, ids, n_all, ops.SCORE_TOKEN_MAJOR, H, D, bs,
-                                              block_stride=values.stride(0))
+            if keys_dense is not None and (keys_dense.stride(2) != 1 or keys_dense.stride(1) != D
+                                           or keys_dense.stride(0) != values.stride(0)):
+                raise RuntimeError("prompt keys must be dense rows laid out like the values")
+            sc = self._formula_block_scores(keys_dense, values, ids, n_all, ops.SCORE_TOKEN_MAJOR,
+                                            ops.SCORE_TOKEN_MAJOR, values.stride(0))
             table.scores.view(-1).index_copy_(0, dst, sc)
         table.set_counts(rows, counts)
 
@@ -732,7 +776,7 @@ class PagedEvictImpl(_ImplBase):
         zero_slots = None
         if self.enabled_paged_eviction:
             seq_lens_arg = dm.seq_kv_lens_tensor
-            dec = self._decode_decision(meta, dm, value_cache)
+            dec = self._decode_decision(meta, dm, value_cache, key_cache)
             if dec["tables"] is not None:
                 block_tables = dec["tables"]
             zero_slots = dec["zero_slots"]
@@ -779,7 +823,7 @@ class PagedEvictImpl(_ImplBase):
                                       max_len, self.kv_cache_dtype, self.num_kv_heads,
                                       self.scale, None, 1.0, 1.0, output=out[n0:])
 
-    def _decode_decision(self, meta, dm, value_cache) -> Dict[str, Any]:
+    def _decode_decision(self, meta, dm, value_cache, key_cache=None) -> Dict[str, Any]:
         """Eviction decision of this decode step: taken by the first layer that runs and reused
         by the others (one launch per step), unless per-layer decisions are requested."""
         step = meta._pe_step
@@ -816,7 +860,8 @@ class PagedEvictImpl(_ImplBase):
         st = getattr(batch, "device_state", None) if batch is not None else None
         if st is not None and not (self.compat.per_layer_decision or self.compat.block_table_slice_in_loop
                                    or self.compat.streaming_decode_original_table):
-            dec = self._decode_decision_device(st, dm, L, table_of, keys, req_ids, value_cache)
+            dec = self._decode_decision_device(st, dm, L, table_of, keys, req_ids, value_cache,
+                                               key_cache)
             step["decode"] = dec
             return dec
         if st is not None:
@@ -892,18 +937,13 @@ class PagedEvictImpl(_ImplBase):
                 rows = staging.upload_i32([table.row_of(k) for k in keys], dev)
                 table.flush_new_rows()
                 new_scores = None
-                if self._tp_exact_scores():
-                    # score of each sequence's just-filled block over ALL KV heads: local token
-                    # sums -> all-reduce -> finish; identical on every rank, so no broadcast
-                    B = len(seq_lens)
+                if self._tp_exact_scores() or self._score_formula() != "value_l2":
+                    # score of each sequence's just-filled block outside the decision launch: over
+                    # ALL KV heads under tensor parallelism (local token sums -> all-reduce ->
+                    # finish; identical on every rank, so no broadcast), or with key norms
                     last = dm.block_tables.gather(
                         1, (nblk.to(torch.int64) - 1).clamp_(min=0).unsqueeze(1)).squeeze(1).contiguous()
-                    sums = ops.block_token_norm_sums(value_cache, last, B, ops.SCORE_CACHE,
-                                                     value_cache.shape[1], value_cache.shape[2], bs,
-                                                     block_stride=value_cache.stride(0))
-                    self._reduce_token_sums(sums)
-                    new_scores = ops.block_score_from_token_sums(sums, B, bs, self.total_num_kv_heads,
-                                                                 value_cache.dtype)
+                    new_scores = self._new_block_scores(key_cache, value_cache, last, len(seq_lens))
                 rmv, tables, _ = ops.evict_select_compact(
                     dm.block_tables, dm.seq_lens_tensor, nblk, method, cfg.cache_budget, bs,
                     cfg.topk_blocks, drop_victim_score=not self.compat.keep_victim_score,
@@ -923,7 +963,7 @@ class PagedEvictImpl(_ImplBase):
         return dec
 
     def _decode_decision_device(self, st, dm, L: np.ndarray, table_of, keys, req_ids,
-                                value_cache) -> Dict[str, Any]:
+                                value_cache, key_cache=None) -> Dict[str, Any]:
         """The budget-type decision on device-resident tables (``DeviceTableState``): the same
         launch as ``_decode_decision`` takes, but the victim's column is closed inside the
         resident row, so there is no second table and nothing about the tables is uploaded.
@@ -982,14 +1022,7 @@ class PagedEvictImpl(_ImplBase):
                 st.score_rows = staging.upload_i32([table.row_of(k) for k in keys], dev)
                 st.score_rows_key = st.key
             table.flush_new_rows()
-            new_scores = None
-            if self._tp_exact_scores():
-                sums = ops.block_token_norm_sums(value_cache, st.last_blocks[:B], B, ops.SCORE_CACHE,
-                                                 value_cache.shape[1], value_cache.shape[2], bs,
-                                                 block_stride=value_cache.stride(0))
-                self._reduce_token_sums(sums)
-                new_scores = ops.block_score_from_token_sums(sums, B, bs, self.total_num_kv_heads,
-                                                             value_cache.dtype)
+            new_scores = self._new_block_scores(key_cache, value_cache, st.last_blocks[:B], B)
             score_kw = dict(drop_victim_score=not self.compat.keep_victim_score,
                             score_layout=(ops.SCORE_CACHE_FLAT if self.compat.score_flat_cache_view
                                           else ops.SCORE_CACHE),

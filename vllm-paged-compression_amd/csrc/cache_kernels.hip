@@ -226,7 +226,7 @@ __global__ void copy_blocks_kernel(void* const* __restrict__ key_ptrs,
 extern "C" {
 
 const char* pe_last_error(void) { return pe::g_last_error; }
-int pe_version(void) { return 103; }  // 103: device-resident table state (pe_table_state_advance, ..._inplace)
+int pe_version(void) { return 104; }  // 104: score formulas (pe_score_formula), PE_SCORE_KEY_CACHE
 
 int pe_device_diagnostics(unsigned int* flags_out, int reset) {
   PE_REQUIRE(flags_out != nullptr, PE_ERR_INVALID_ARG, "device_diagnostics: null pointer");
