@@ -42,7 +42,7 @@ MFMA_PEAK_TFLOPS = 2500.0  # dense bf16/fp16 matrix peak (no sparsity)
 PRESETS = {
     "c1": dict(num_prompts=1, input_len=1024, output_len=100, evict=0.0, alt_evict=0.0, layers=12,
                num_heads=12, num_kv_heads=12, head_size=64, dtype="fp16", prefill_batch=1,
-               model="OPT-125m"),
+               model="OPT-125m", graph_decode=True),
     "c2": dict(),
     "c3": dict(num_prompts=64, input_len=8192, output_len=1024, evict=0.5, alt_evict=0.0, steps=1,
                warmup=1),
@@ -110,6 +110,12 @@ def parse():
                     help="vectorised scheduler with the block tables kept on the host and uploaded "
                          "every decode step (default: tables resident on the GPU, one int per "
                          "sequence uploaded per step)")
+    ap.add_argument("--graph-decode", action="store_true",
+                    help="replay the attention launches of a decode step (all layers) from a HIP graph "
+                         "captured on the first step that evicts nothing; steps with an eviction "
+                         "decision run eagerly.  Needs the resident tables (the captured launches "
+                         "read the step's metadata from the same device buffers every step).  Pays "
+                         "when the step is launch-bound (few sequences)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--alt-evict", type=float, default=0.5,
                     help="second eviction fraction measured after the timed region and reported under "
@@ -233,6 +239,36 @@ class Workload:
             ops.prefill_event_sink = None
             self.timed_prefill += [(s, e, prefill_flops) for s, e in sink]
 
+    def _capture_decode(self, meta, max_len: int):
+        """The attention launches of one decode step, all layers, captured into a HIP graph.  The
+        step's metadata tensors are the scheduler's resident device buffers, so later steps
+        replay the same launches on new contents; the length that sizes the KV splits is fixed
+        at the generation's maximum."""
+        meta.max_decode_seq_len = max_len
+        dm = meta.decode_metadata
+        if dm is not None and dm is not meta:
+            dm.max_decode_seq_len = max_len
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                for li, impl in enumerate(self.impls):
+                    impl.forward(self.qd, self.kd, self.vd, self.kv[li], meta)
+        torch.cuda.current_stream().wait_stream(side)
+        return graph
+
+    def _replay_decode(self, graph, decode_bytes: int) -> None:
+        if self.timing_on:
+            s_ev = torch.cuda.Event(enable_timing=True)
+            e_ev = torch.cuda.Event(enable_timing=True)
+            s_ev.record()
+            graph.replay()
+            e_ev.record()
+            self.timed.append((s_ev, e_ev, decode_bytes, len(self.impls)))
+        else:
+            graph.replay()
+
     def _prefill_flops(self, n_req: int) -> float:
         """4 * Hq * D * sum_i min(i+1, L_kv) per request: both contractions, causal, the kv length
         being the pruned one when the prompt is pruned before attention."""
@@ -259,6 +295,7 @@ class Workload:
             return self._generate_per_request()
         import numpy as np
         from vllm_paged_compression_amd.batch_scheduler import BatchEvictionScheduler
+        from vllm_paged_compression_amd.page_evict_kv_util import budget_decode_trigger
         a, bs = self.a, self.bs
         B, L0 = a.num_prompts, a.input_len
         sched = BatchEvictionScheduler(bs, self.num_blocks, self.cfg, max_seqs=B,
@@ -283,6 +320,8 @@ class Workload:
         # decode: one vectorised scheduler step + one metadata build per step
         L = L0
         es = 2
+        use_graph = a.graph_decode and not a.host_tables and not self.allreduce and not self.percentage
+        graph, warmed = None, False
         for it in range(a.output_len):
             batch = sched.schedule_decode(rids)
             L += 1
@@ -295,9 +334,19 @@ class Workload:
                 self._progress(f"decode step {it + 1}/{a.output_len}")
             nbytes = int((2 * kv_adj * self.Hkv * self.D * es + -(-kv_adj // bs) * 4).sum()) \
                 + 2 * B * self.Hq * self.D * es
-            self._layers(self.qd, self.kd, self.vd, meta, self.o_partial_d, decode_bytes=nbytes)
-            if self.cfg is not None:
-                sched.commit(self.impls[0].get_rmv_block_idx())
+            # a step whose sequences all stay below their eviction trigger launches nothing but
+            # the layers' attention, always on the same device buffers: it can be replayed
+            plain = self.cfg is None or (self.cfg.evict_method in ("streamingLLM", "global", "local")
+                                         and not budget_decode_trigger(self.cfg, L, bs))
+            if use_graph and plain and warmed:
+                if graph is None:
+                    graph = self._capture_decode(meta, L0 + a.output_len)
+                self._replay_decode(graph, nbytes)
+            else:
+                self._layers(self.qd, self.kd, self.vd, meta, self.o_partial_d, decode_bytes=nbytes)
+                warmed = True
+                if self.cfg is not None:
+                    sched.commit(self.impls[0].get_rmv_block_idx())
             used = self.num_blocks - sched.get_num_free_gpu_blocks()
             self.kv_blocks_peak = max(self.kv_blocks_peak, used)
         for r in rids:
@@ -618,8 +667,14 @@ def main():
             "world_size": dist.get_world_size() if world > 1 else 1,
             "dist_backend": (dist.get_backend() if world > 1 else None),
             "devices": devices,
-            "oproj_allreduce": bool(wl.allreduce), **kv},
+            "oproj_allreduce": bool(wl.allreduce),
+            "graph_decode": bool(a.graph_decode and not a.host_tables and not wl.allreduce
+                                 and not wl.percentage), **kv},
     }
+    if os.environ.get("PE_BENCH_KV_CHECKSUM"):
+        # bit-level sum of every layer's KV cache after the last generation (A/B of launch modes)
+        out["config"]["kv_checksum"] = int(sum(int(t.view(torch.int16).to(torch.int64).sum().item())
+                                               for t in wl.kv))
     main_budget = wl.budget
     del wl
     torch.cuda.empty_cache()

@@ -78,3 +78,23 @@ def test_bench_presets_select_the_baseline_configs():
             "--output-len", "20", "--layers", "2")
     assert "Hq 64, Hkv 8" in d["config"]["workload"] and "TP=8" in d["config"]["workload"]
     assert "budget 3072 (25% eviction)" in d["config"]["workload"]
+
+
+@pytest.mark.parametrize("extra", [["--evict", "0"], [], ["--decode-evict-method", "streamingLLM"]])
+def test_bench_graph_decode_leaves_the_same_kv_cache(extra):
+    """--graph-decode replays the attention launches of the decode steps that evict nothing from
+    a HIP graph; the KV caches of all layers must end bit-identical to the eager run's, with the
+    same blocks held (evictions still happen, on their eager steps)."""
+    env = dict(os.environ, PE_BENCH_KV_CHECKSUM="1")
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0",
+            "--num-prompts", "4", "--prefill-batch", "4", "--input-len", "200", "--output-len", "70",
+            "--layers", "3", "--no-cpu-baseline", "--alt-evict", "0", *extra]
+    res = []
+    for mode in ([], ["--graph-decode"]):
+        out = subprocess.run(base + mode, capture_output=True, text=True, timeout=280, cwd=ROOT, env=env)
+        assert out.returncode == 0, out.stderr[-2000:]
+        d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+        res.append(d["config"])
+    assert res[0]["graph_decode"] is False and res[1]["graph_decode"] is True
+    assert res[0]["kv_checksum"] == res[1]["kv_checksum"] != 0
+    assert res[0]["kv_gb_held_peak"] == res[1]["kv_gb_held_peak"]
