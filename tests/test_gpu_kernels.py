@@ -165,6 +165,12 @@ DECODE_CASES = [
     (8, 2, 64, 8, torch.float16, [9, 130]),           # generic path (block size)
     (8, 2, 128, 16, torch.float32, [50, 333]),        # generic path (f32)
     (34, 2, 128, 16, torch.bfloat16, [70, 200]),      # 17 query heads per KV head -> generic
+    # the remaining head sizes of the reference's sweep (tests/kernels/test_attention.py:30)
+    (8, 2, 96, 16, torch.bfloat16, [45, 260]),
+    (8, 8, 112, 16, torch.float16, [129, 16]),
+    (6, 2, 120, 16, torch.bfloat16, [200, 31]),
+    (8, 2, 192, 16, torch.bfloat16, [90, 513]),
+    (8, 2, 192, 32, torch.float16, [65, 300]),
 ]
 
 
@@ -426,6 +432,11 @@ PREFILL_CASES = [
     (8, 8, 64, torch.bfloat16, [150], [100]),
     (4, 4, 80, torch.bfloat16, [70, 33], [48, 33]),     # generic path
     (4, 2, 64, torch.float32, [50], [50]),               # generic path
+    (4, 2, 96, torch.bfloat16, [90, 17], [60, 17]),      # generic path
+    (4, 4, 112, torch.float16, [65], [65]),              # generic path
+    (6, 2, 120, torch.bfloat16, [40, 130], [40, 100]),   # generic path
+    (4, 1, 192, torch.bfloat16, [150], [150]),           # generic path
+    (8, 2, 256, torch.float16, [70, 129], [70, 96]),     # generic path
 ]
 
 
