@@ -29,13 +29,17 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libpe_oracle.so")
+# PE_ORACLE_LIB: a differently built copy of the same source (tools/sanitize_oracle.sh builds one
+# with the undefined-behaviour sanitizer and runs the CPU tests through it)
+_LIB_PATH = os.environ.get("PE_ORACLE_LIB") or os.path.join(_HERE, "libpe_oracle.so")
 _DT = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 
 
 def build(force: bool = False) -> str:
     """Compile oracle/pe_oracle.c with gcc (a few seconds)."""
     src = os.path.join(_HERE, "pe_oracle.c")
+    if os.environ.get("PE_ORACLE_LIB"):
+        return _LIB_PATH
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(src) > os.path.getmtime(_LIB_PATH):
         subprocess.check_call(
             ["gcc", "-O2", "-fPIC", "-shared", "-std=c11", "-fno-fast-math", "-ffp-contract=off",
