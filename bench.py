@@ -116,6 +116,13 @@ def parse():
                          "decision run eagerly.  Needs the resident tables (the captured launches "
                          "read the step's metadata from the same device buffers every step).  Pays "
                          "when the step is launch-bound (few sequences)")
+    ap.add_argument("--rope", choices=["off", "separate", "fused"], default="off",
+                    help="also run the rotary embedding that precedes attention in the model "
+                         "(llama.py:202-203) on every layer's query/key rows: separate = its own "
+                         "launch in front of the backend (the reference's order), fused = handed to "
+                         "the backend, which rotates a decode layer's rows inside the attention launch "
+                         "(pe_decode_step_rope).  off (default) = the headline workload, rows arrive "
+                         "rotated")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--alt-evict", type=float, default=0.5,
                     help="second eviction fraction measured after the timed region and reported under "
@@ -197,6 +204,15 @@ class Workload:
                 parallel.enable_one_shot_all_reduce(tp_group, dev, 1 << 20)
             self.o_partial_p = torch.zeros(Tp, self.hidden, dtype=self.dtype, device=dev)
             self.o_partial_d = torch.zeros(B, self.hidden, dtype=self.dtype, device=dev)
+        self.cos_sin = None
+        if a.rope != "off":
+            # cos/sin table of the model's rotary embedding (rot_dim = head size, NeoX pairing)
+            max_pos = a.input_len + a.output_len + 1
+            inv = 1.0 / (10000.0 ** (torch.arange(0, self.D, 2, dtype=torch.float32) / self.D))
+            fr = torch.outer(torch.arange(max_pos, dtype=torch.float32), inv)
+            self.cos_sin = torch.cat([fr.cos(), fr.sin()], dim=-1).to(self.dtype).to(dev)
+            self.pos_p = torch.arange(a.input_len, dtype=torch.int64, device=dev).repeat(a.prefill_batch)
+            self.pos_d = torch.zeros(B, dtype=torch.int64, device=dev)
         # decode-kernel timing (HIP events on the launch stream) of one layer
         self.timed = []          # (start_event, end_event, algorithmic_bytes)
         self.timed_prefill = []  # (start_event, end_event, flops) per prefill-attention launch
@@ -213,14 +229,17 @@ class Workload:
     def _build(self, inter, seq_lens, q_lens):
         return self._builder(inter).build(seq_lens, q_lens, -1, len(seq_lens))
 
-    def _layers(self, q, k, v, meta, o_partial, decode_bytes=None, prefill_flops=None):
+    def _layers(self, q, k, v, meta, o_partial, decode_bytes=None, prefill_flops=None, positions=None):
         """All layers of one step.  For decode steps of the timed region, layers 1..L-1 (layer 0
         also carries the step's eviction launch) are bracketed by one pair of HIP events on the
         launch stream: every launch between them is the decode-attention kernel, so the span
         divided by the launch count is that kernel's average launch duration."""
         from vllm_paged_compression_amd import ops, parallel
         span = (decode_bytes is not None and self.timing_on and not self.allreduce
-                and len(self.impls) > 2)
+                and len(self.impls) > 2 and self.a.rope != "separate")
+        rope = None
+        if self.cos_sin is not None:
+            rope = (positions, self.cos_sin, True)
         sink = None
         if prefill_flops is not None and self.timing_on:
             sink = ops.prefill_event_sink = []
@@ -228,7 +247,13 @@ class Workload:
             if span and li == 1:
                 s_ev = torch.cuda.Event(enable_timing=True)
                 s_ev.record()
-            impl.forward(q, k, v, self.kv[li], meta)
+            if rope is not None and self.a.rope == "separate":
+                ops.rotary_embedding(positions, q, k, self.D, self.cos_sin, True)
+                impl.forward(q, k, v, self.kv[li], meta)
+            elif rope is not None:
+                impl.forward(q, k, v, self.kv[li], meta, rope=rope)
+            else:
+                impl.forward(q, k, v, self.kv[li], meta)
             if self.allreduce:
                 parallel.all_reduce_sum(o_partial, self.tp_group)
         if span:
@@ -315,12 +340,14 @@ class Workload:
             meta = self._build(inter, [L0] * len(grp), [L0] * len(grp))
             T = len(grp) * L0
             self._layers(self.qp[:T], self.kp[:T], self.vp[:T], meta, self._op(self.o_partial_p, T),
-                         prefill_flops=self._prefill_flops(len(grp)))
+                         prefill_flops=self._prefill_flops(len(grp)),
+                         positions=None if self.cos_sin is None else self.pos_p[:T])
         self._progress("prefill done")
         # decode: one vectorised scheduler step + one metadata build per step
         L = L0
         es = 2
-        use_graph = a.graph_decode and not a.host_tables and not self.allreduce and not self.percentage
+        use_graph = a.graph_decode and not a.host_tables and not self.allreduce and not self.percentage \
+            and a.rope == "off"
         graph, warmed = None, False
         for it in range(a.output_len):
             batch = sched.schedule_decode(rids)
@@ -338,12 +365,15 @@ class Workload:
             # the layers' attention, always on the same device buffers: it can be replayed
             plain = self.cfg is None or (self.cfg.evict_method in ("streamingLLM", "global", "local")
                                          and not budget_decode_trigger(self.cfg, L, bs))
+            if self.cos_sin is not None:
+                self.pos_d.fill_(L - 1)      # position of the step's token
             if use_graph and plain and warmed:
                 if graph is None:
                     graph = self._capture_decode(meta, L0 + a.output_len)
                 self._replay_decode(graph, nbytes)
             else:
-                self._layers(self.qd, self.kd, self.vd, meta, self.o_partial_d, decode_bytes=nbytes)
+                self._layers(self.qd, self.kd, self.vd, meta, self.o_partial_d, decode_bytes=nbytes,
+                             positions=None if self.cos_sin is None else self.pos_d)
                 warmed = True
                 if self.cfg is not None:
                     sched.commit(self.impls[0].get_rmv_block_idx())
@@ -373,7 +403,8 @@ class Workload:
             meta = self._build(inter, [L0] * len(grp), [L0] * len(grp))
             T = len(grp) * L0
             self._layers(self.qp[:T], self.kp[:T], self.vp[:T], meta, self._op(self.o_partial_p, T),
-                         prefill_flops=self._prefill_flops(len(grp)))
+                         prefill_flops=self._prefill_flops(len(grp)),
+                         positions=None if self.cos_sin is None else self.pos_p[:T])
         # decode
         L = L0
         for _ in range(a.output_len):
@@ -391,7 +422,10 @@ class Workload:
             es = 2
             nbytes = sum(2 * kvl * self.Hkv * self.D * es + -(-kvl // bs) * 4 for kvl in kv_adj) \
                 + 2 * B * self.Hq * self.D * es
-            self._layers(self.qd, self.kd, self.vd, meta, self.o_partial_d, decode_bytes=nbytes)
+            if self.cos_sin is not None:
+                self.pos_d.fill_(L - 1)
+            self._layers(self.qd, self.kd, self.vd, meta, self.o_partial_d, decode_bytes=nbytes,
+                         positions=None if self.cos_sin is None else self.pos_d)
             if self.cfg is not None:
                 sched.commit(self.impls[0].get_rmv_block_idx())
             used = self.num_blocks - bm.get_num_free_gpu_blocks()
@@ -636,7 +670,9 @@ def main():
                 "avg_launch_us": round(avg_t * 1e6, 2),
                 "algorithmic_bytes_per_launch": int(avg_b),
                 "launches_timed": sum(n for _, _, _, n in wl.timed),
-                "includes": "fused KV write of the step's token (pe_decode_step)"}
+                "includes": "fused KV write of the step's token (pe_decode_step)"
+                            + (" and the rotary embedding of its query/key rows (pe_decode_step_rope)"
+                               if a.rope == "fused" else "")}
     roof_p = None
     if wl.timed_prefill:
         pd = [s.elapsed_time(e) * 1e-3 for s, e, _ in wl.timed_prefill]
@@ -667,9 +703,9 @@ def main():
             "world_size": dist.get_world_size() if world > 1 else 1,
             "dist_backend": (dist.get_backend() if world > 1 else None),
             "devices": devices,
-            "oproj_allreduce": bool(wl.allreduce),
+            "oproj_allreduce": bool(wl.allreduce), "rope": a.rope,
             "graph_decode": bool(a.graph_decode and not a.host_tables and not wl.allreduce
-                                 and not wl.percentage), **kv},
+                                 and not wl.percentage and a.rope == "off"), **kv},
     }
     if os.environ.get("PE_BENCH_KV_CHECKSUM"):
         # bit-level sum of every layer's KV cache after the last generation (A/B of launch modes)

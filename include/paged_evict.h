@@ -184,6 +184,33 @@ int pe_decode_step(void* out, const void* query, const void* new_key, const void
                    float scale, int max_seq_len, int dtype, void* workspace,
                    int64_t workspace_bytes, void* stream);
 
+/* pe_decode_step_rope: pe_decode_step with the rotary embedding of the step's query and key rows
+ * done inside the launch.  Replaces the three launches the reference issues per layer of a decode
+ * step: rotary_embedding (csrc/pos_encoding_kernels.cu:124-162, called from
+ * vllm/model_executor/models/llama.py:202-203), reshape_and_cache and paged_attention_v1/v2
+ * (vllm/attention/backends/torch_cuda_sdpa.py:936,947,1049-1062).  query and new_key are given
+ * UNROTATED and are left as they are (the reference rotates them in place; nothing after
+ * attention reads them); the rotated key row is what the cache receives.  positions int64
+ * [num_seqs] (clamped to [0, max_position)), cos_sin_cache [max_position, rot_dim] of the storage
+ * type (a row = rot_dim/2 cosines then rot_dim/2 sines), is_neox as in rotary_embedding.  The
+ * arithmetic is that of pe_rope_reshape_and_cache (each product and their sum rounded to the
+ * storage type), so the result and the cache bytes equal those of pe_rope_reshape_and_cache
+ * followed by pe_paged_decode.  A sequence whose slot is negative is not cached, its query is
+ * still rotated and its new key row is ignored, as in pe_decode_step.  rot_dim must be a multiple
+ * of 64 (NeoX pairing) or 16 (GPT-J pairing), head_size 64 or 128, and the shape one
+ * pe_paged_decode_supports_fused_write accepts; otherwise PE_ERR_UNSUPPORTED, nothing written. */
+int pe_decode_step_rope(void* out, const void* query, const void* new_key, const void* new_value,
+                        void* key_cache, void* value_cache, const int64_t* slot_mapping,
+                        const int32_t* block_tables, const int32_t* seq_lens,
+                        const float* alibi_slopes, const int64_t* positions,
+                        const void* cos_sin_cache, int rot_dim, int is_neox, int64_t max_position,
+                        int num_seqs, int num_heads, int num_kv_heads, int head_size,
+                        int block_size, int64_t num_blocks, int max_num_blocks_per_seq,
+                        int64_t q_stride, int64_t new_k_stride, int64_t new_v_stride,
+                        int64_t kv_block_stride, int64_t kv_head_stride, float scale,
+                        int max_seq_len, int dtype, void* workspace, int64_t workspace_bytes,
+                        void* stream);
+
 /* pe_paged_decode_noalloc: pe_paged_decode without a caller workspace.  It has no counterpart
  * in the reference; it exists for callers that cannot allocate device memory around the call
  * (code under HIP-graph capture, tight serving loops, harnesses that forbid hipMalloc).  The

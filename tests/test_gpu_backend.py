@@ -410,3 +410,90 @@ def test_streaming_decode_table_on_eviction_steps(oracle, head_compat):
         evictions += len(got)
         sched.commit(got)
     assert evictions == 2
+
+
+@pytest.mark.parametrize("method", ["global", "streamingLLM-1"])
+def test_backend_forward_with_rope(oracle, method):
+    """forward(..., rope=(positions, cos_sin_cache, is_neox)) on unrotated query/key rows equals
+    rotary embedding (the separate op) followed by forward(): outputs and KV caches bit for bit,
+    over a prefill step and decode steps that include eviction steps.  'global' decodes on the
+    one-launch path (rotation inside the attention kernel: query/key must stay unrotated),
+    'streamingLLM-1' zeroes a slot per eviction step, which takes the separate-launch path
+    (query/key rotated in place)."""
+    from test_oracle_golden import rope_cache
+    from vllm_paged_compression_amd import ops
+    from vllm_paged_compression_amd.backend import PagedEvictBackend
+    from vllm_paged_compression_amd.batch_scheduler import BatchEvictionScheduler
+    from vllm_paged_compression_amd.config import CacheConfigView, PagedEvictConfig
+
+    g = torch.Generator().manual_seed(77)
+    Hq, Hkv, D, L_layers, nb = 8, 2, 128, 2, 96
+    budget, n_decode, max_pos = 128, 40, 1024
+    cfg = PagedEvictConfig(True, "budget", method, budget, 3)
+    cache_cfg = CacheConfigView(BS, cfg)
+    impl_cls = PagedEvictBackend.get_impl_cls()
+    cs = rope_cache(max_pos, D, torch.bfloat16).cuda()
+    prompts = {"r0": 200, "r1": 130, "r2": 90}
+    lens = list(prompts.values())
+    B = len(lens)
+
+    class Side:
+        def __init__(self):
+            self.impls = [impl_cls(Hq, D, D ** -0.5, Hkv, None, None, "auto", None, None,
+                                   cache_config=cache_cfg, prefix=f"model.layers.{i}.self_attn.attn",
+                                   max_num_seqs=8, max_blocks_per_seq=64) for i in range(L_layers)]
+            shape = PagedEvictBackend.get_kv_cache_shape(nb, BS, Hkv, D)
+            self.kv = [torch.zeros(shape, dtype=torch.bfloat16, device="cuda") for _ in range(L_layers)]
+            self.sched = BatchEvictionScheduler(BS, nb, cfg, max_seqs=8, max_blocks_per_seq=64)
+            for i, (rid, n) in enumerate(prompts.items()):
+                self.sched.add_request(rid, i, n)
+
+        def prefill_meta(self):
+            inter = [SimpleNamespace(request_id=rid, is_prompt=True,
+                                     block_tables={i: self.sched.get_block_table(rid)},
+                                     seq_kv_lens={i: self.sched.get_seq_kv_len(rid)}, seq_ids=[i],
+                                     input_tokens=[[0] * n], orig_seq_lens=[n], seq_lens=[n],
+                                     query_lens=[n], context_lens=[0])
+                     for i, (rid, n) in enumerate(prompts.items())]
+            return _builder(cfg, inter).build(lens, lens, -1, B)
+
+    fused, split = Side(), Side()
+    T = sum(lens)
+    pos_p = torch.cat([torch.arange(n) for n in lens]).cuda()
+    meta_f, meta_s = fused.prefill_meta(), split.prefill_meta()
+    for li in range(L_layers):
+        q, k, v = (t.cuda() for t in _mk_inputs(T, Hq, Hkv, D, g))
+        q2, k2 = q.clone(), k.clone()
+        out_f = fused.impls[li].forward(q, k, v, fused.kv[li], meta_f, rope=(pos_p, cs, True))
+        ops.rotary_embedding(pos_p, q2, k2, D, cs, True)
+        out_s = split.impls[li].forward(q2, k2, v, split.kv[li], meta_s)
+        assert torch.equal(q, q2) and torch.equal(k, k2)      # prompt rows are rotated in place
+        assert torch.equal(out_f, out_s) and torch.equal(fused.kv[li], split.kv[li])
+    rids = list(prompts)
+    L = dict(zip(rids, lens))
+    evictions = 0
+    for step in range(n_decode):
+        bf, bsp = fused.sched.schedule_decode(rids), split.sched.schedule_decode(rids)
+        meta_f = _builder(cfg, []).build_decode_batch(bf)
+        meta_s = _builder(cfg, []).build_decode_batch(bsp)
+        pos = torch.tensor([L[r] for r in rids], dtype=torch.int64).cuda()   # position of the new token
+        for r in rids:
+            L[r] += 1
+        for li in range(L_layers):
+            q, k, v = (t.cuda() for t in _mk_inputs(B, Hq, Hkv, D, g))
+            q0, k0 = q.clone(), k.clone()
+            q2, k2 = q.clone(), k.clone()
+            out_f = fused.impls[li].forward(q, k, v, fused.kv[li], meta_f, rope=(pos, cs, True))
+            ops.rotary_embedding(pos, q2, k2, D, cs, True)
+            out_s = split.impls[li].forward(q2, k2, v, split.kv[li], meta_s)
+            assert torch.equal(out_f, out_s), (step, li)
+            assert torch.equal(fused.kv[li], split.kv[li]), (step, li)
+            if method == "global":
+                assert torch.equal(q, q0) and torch.equal(k, k0), "one-launch path rotates in registers"
+        got_f, got_s = fused.impls[0].get_rmv_block_idx(), split.impls[0].get_rmv_block_idx()
+        assert got_f == got_s
+        evictions += len(got_f)
+        fused.sched.commit(got_f)
+        split.sched.commit(got_s)
+    assert evictions >= 3
+    ops.check_device_diagnostics()

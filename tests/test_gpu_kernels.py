@@ -591,6 +591,21 @@ def test_prompt_token_select_batch_with_ties(ops, oracle, method, dtype):
 
 
 # ------------------------------------------------------------------ fused decode step
+def disjoint_tables(lens, bs, nb, g):
+    """Block tables whose rows share no block, as a block manager hands them out: the fused step
+    stores a sequence's new token while other workgroups of the launch are reading, so a block
+    that two rows used would be read by one row while the other writes into it."""
+    need = [-(-L // bs) for L in lens]
+    assert sum(need) <= nb
+    perm = torch.randperm(nb, generator=g).to(torch.int32)
+    bt = torch.zeros(len(lens), max(need) + 1, dtype=torch.int32)
+    at = 0
+    for i, n in enumerate(need):
+        bt[i, :n] = perm[at:at + n]
+        at += n
+    return bt
+
+
 @pytest.mark.parametrize("Hq,Hkv,D,dtype", [(32, 8, 128, torch.bfloat16), (12, 12, 64, torch.float16),
                                             (8, 1, 128, torch.bfloat16)])
 @pytest.mark.parametrize("splits", [0, 3])
@@ -608,8 +623,7 @@ def test_decode_step_fused_write(ops, oracle, Hq, Hkv, D, dtype, splits, monkeyp
     q = ((torch.rand(S, Hq, D, generator=g) * 2 - 1) * sc).to(dtype)
     k = ((torch.rand(S, Hkv, D, generator=g) * 2 - 1) * sc).to(dtype)
     v = ((torch.rand(S, Hkv, D, generator=g) * 2 - 1) * sc).to(dtype)
-    M = max(lens) // bs + 1
-    bt = torch.stack([torch.randperm(nb, generator=g)[:M] for _ in range(S)]).to(torch.int32)
+    bt = disjoint_tables(lens, bs, nb, g)
     slots = torch.tensor([int(bt[i, (L - 1) // bs]) * bs + (L - 1) % bs for i, L in enumerate(lens)],
                          dtype=torch.int64)
     slots[1] = -1                                     # padding token: nothing written
@@ -747,6 +761,72 @@ def test_rope_reshape_and_cache(ops, oracle, dtype, is_neox, Hq, Hkv, D, rot):
     assert torch.equal(q2, qd) and torch.equal(k2, kd)
     # empty batch
     ops.rotary_embedding(pos[:0].cuda(), q2[:0], k2[:0], D, cs.cuda(), is_neox)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("is_neox", [True, False])
+@pytest.mark.parametrize("Hq,Hkv,D,rot", [(32, 8, 128, 128), (12, 12, 64, 64), (8, 1, 128, 64),
+                                          (8, 2, 128, 48)])
+@pytest.mark.parametrize("splits", [0, 3])
+def test_decode_step_rope(ops, oracle, dtype, is_neox, Hq, Hkv, D, rot, splits, monkeypatch):
+    """One launch (rotary embedding + KV write + attention) == the oracle's rotary embedding, KV
+    write and paged attention: the cache receives the rotated key byte for byte, the output equals
+    the two-launch form (rotary_embedding_and_cache, then decode_step's unfused twin) bit for bit
+    and the oracle within the kernel tolerance; query and key stay unrotated.  rot 48 is a partial
+    rotation the NeoX pairing cannot keep in one lane: refused, GPT-J pairing serves it."""
+    from test_oracle_golden import rope_cache
+    if splits:
+        monkeypatch.setenv("PE_DECODE_SPLITS", str(splits))
+    g = torch.Generator().manual_seed(Hq + D + rot + int(is_neox))
+    bs, nb, max_pos = 16, 400, 4096
+    lens = [1, 16, 17, 32, 33, 700, 784, 2000]       # kv length including the new token
+    S = len(lens)
+    sc = D ** -0.5
+    cs = rope_cache(max_pos, rot, dtype)
+    pos = torch.randint(0, max_pos, (S,), generator=g)
+    pos[0], pos[1] = 0, max_pos - 1
+    kc, vc = make_cache(nb, Hkv, D, bs, dtype, g)
+    qkv = ((torch.rand(S, (Hq + 2 * Hkv) * D, generator=g) * 2 - 1) * 4 * sc).to(dtype)
+    q, k, v = (t.reshape(S, -1, D) for t in qkv.split([Hq * D, Hkv * D, Hkv * D], dim=-1))
+    bt = disjoint_tables(lens, bs, nb, g)
+    slots = torch.tensor([int(bt[i, (L - 1) // bs]) * bs + (L - 1) % bs for i, L in enumerate(lens)],
+                         dtype=torch.int64)
+    slots[2] = -1                                     # padding token: nothing written
+    lens_t = torch.tensor(lens, dtype=torch.int32)
+    qkv_d = qkv.cuda()
+    qd, kd, vd = (t.reshape(S, -1, D) for t in qkv_d.split([Hq * D, Hkv * D, Hkv * D], dim=-1))
+    kc_d, vc_d = kc.cuda(), vc.cuda()
+    out = torch.empty(S, Hq, D, dtype=dtype, device="cuda")
+    args = (out, pos.cuda(), qd, kd, vd, kc_d, vc_d, slots.cuda(), Hkv, sc, bt.cuda(), lens_t.cuda(), bs,
+            max(lens), cs.cuda(), is_neox)
+    if is_neox and rot % 64:
+        assert not ops.decode_step_rope_supported(Hq, Hkv, D, bs, dtype, rot, is_neox)
+        with pytest.raises(RuntimeError, match="not supported"):
+            ops.decode_step_rope(*args)
+        assert torch.equal(kc_d.cpu(), kc)            # refused before anything was written
+        return
+    assert ops.decode_step_rope_supported(Hq, Hkv, D, bs, dtype, rot, is_neox)
+    ops.decode_step_rope(*args)
+    assert torch.equal(qkv_d.cpu(), qkv)              # inputs are left unrotated
+    # oracle: rotate, write, attend
+    q_ref = oracle.rotary_embedding(pos, q.reshape(S, -1), D, cs, is_neox).reshape(S, Hq, D)
+    k_ref = oracle.rotary_embedding(pos, k.reshape(S, -1), D, cs, is_neox).reshape(S, Hkv, D)
+    kc_ref, vc_ref = kc.clone(), vc.clone()
+    oracle.reshape_and_cache(k_ref, v.contiguous(), kc_ref, vc_ref, slots)
+    ref = oracle.paged_attention(q_ref, kc_ref, vc_ref, bt, lens_t, sc)
+    assert torch.equal(kc_d.cpu(), kc_ref) and torch.equal(vc_d.cpu(), vc_ref)
+    torch.testing.assert_close(out.cpu().float(), ref.float(), atol=ATOL[dtype], rtol=RTOL[dtype])
+    # the separate launches on the same inputs: rotation in place + KV write, then the fused
+    # write/attention step on the rotated rows with nothing left to write differently
+    qkv_2 = qkv.cuda()
+    q2, k2, v2 = (t.reshape(S, -1, D) for t in qkv_2.split([Hq * D, Hkv * D, Hkv * D], dim=-1))
+    kc_2, vc_2 = kc.cuda(), vc.cuda()
+    ops.rotary_embedding(pos.cuda(), q2, k2, D, cs.cuda(), is_neox)
+    out2 = torch.empty_like(out)
+    ops.decode_step(out2, q2, k2, v2, kc_2, vc_2, slots.cuda(), Hkv, sc, bt.cuda(), lens_t.cuda(), bs,
+                    max(lens))
+    assert torch.equal(kc_2, kc_d) and torch.equal(vc_2, vc_d)
+    assert torch.equal(out2, out)
 
 
 def test_device_diagnostics_report_clamps(oracle):

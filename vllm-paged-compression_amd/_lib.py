@@ -34,6 +34,11 @@ SIGNATURES = {
                                c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                c_int64, c_int, c_int64, c_int64, c_int64, c_int64, c_int64, c_float,
                                c_int, c_int, c_void_p, c_int64, c_void_p]),
+    "pe_decode_step_rope": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_int, c_int, c_int64, c_int, c_int, c_int, c_int, c_int,
+                                    c_int64, c_int, c_int64, c_int64, c_int64, c_int64, c_int64,
+                                    c_float, c_int, c_int, c_void_p, c_int64, c_void_p]),
     "pe_prefill_causal": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64,
                                   c_int64, c_float, c_int, c_void_p]),

@@ -521,9 +521,17 @@ class PagedEvictImpl(_ImplBase):
     def forward(self, query: torch.Tensor, key: torch.Tensor, value: torch.Tensor,
                 kv_cache: torch.Tensor, attn_metadata: PagedEvictMetadata, k_scale: float = 1.0,
                 v_scale: float = 1.0, attn_type: str = AttentionType.DECODER,
-                output: Optional[torch.Tensor] = None) -> torch.Tensor:
+                output: Optional[torch.Tensor] = None,
+                rope: Optional[Tuple[torch.Tensor, torch.Tensor, bool]] = None) -> torch.Tensor:
         """query [T, Hq*D], key/value [T, Hkv*D], kv_cache [2, nb, bs*Hkv*D] (numel()==0 in the
-        profiling run) -> [T, Hq*D]."""
+        profiling run) -> [T, Hq*D].
+
+        ``rope`` = (positions int64 [T], cos_sin_cache [max_position, rot_dim], is_neox) hands
+        the rotary embedding that precedes attention in the model
+        (vllm/model_executor/models/llama.py:202-203) to the backend: query and key then arrive
+        UNROTATED.  Prompt rows are rotated in place before the prefill path; a decode layer on
+        the one-launch path rotates inside the attention kernel (pe_decode_step_rope) and leaves
+        query/key as they are, any other decode layer rotates in place first."""
         assert k_scale == 1.0 and v_scale == 1.0
         if attn_type != AttentionType.DECODER:
             raise NotImplementedError("Paged eviction is only enabled for decoder attention")
@@ -542,7 +550,7 @@ class PagedEvictImpl(_ImplBase):
                     kc, vc = PagedAttention.split_kv_cache(kv_cache, self.num_kv_heads, self.head_size)
                     self.kv_cache_pruner.merge_blocks_in_cache(kc, vc, dec["merge_tables"], dec["merge"])
             o = torch.empty_like(query) if output is None else output
-            launcher.run(query, key, value, kv_cache, o)
+            launcher.run(query, key, value, kv_cache, o, rope)
             return o
         query = query.view(-1, self.num_heads, self.head_size)
         key = key.view(-1, self.num_kv_heads, self.head_size)
@@ -566,12 +574,20 @@ class PagedEvictImpl(_ImplBase):
                 self.block_l2norm_mgr.update_reqs(attn_metadata.reqid_mapping_blocktables)
             attn_metadata._pe_step.setdefault("mgr", self.block_l2norm_mgr)
 
+        rope_dec = None
+        if rope is not None:
+            positions, cos_sin, is_neox = rope
+            nt = attn_metadata.num_prefill_tokens
+            if nt > 0:
+                ops.rotary_embedding(positions[:nt], query[:nt], key[:nt], self.head_size, cos_sin,
+                                     is_neox)
+            rope_dec = (positions[nt:], cos_sin, is_neox)
         if (pm := attn_metadata.prefill_metadata) is not None:
             self._forward_prefill(out, query, key, value, key_cache, value_cache, attn_metadata, pm,
                                   is_profile_run)
         if (dm := attn_metadata.decode_metadata) is not None:
             self._forward_decode(out, query, key, value, key_cache, value_cache, attn_metadata, dm,
-                                 kv_cache)
+                                 kv_cache, rope_dec)
         return out.view(T, self.num_heads * self.head_size)
 
     # ------------------------------------------------------------------------------ prefill
@@ -768,7 +784,7 @@ class PagedEvictImpl(_ImplBase):
 
     # ------------------------------------------------------------------------------- decode
     def _forward_decode(self, out, query, key, value, key_cache, value_cache, meta, dm,
-                        kv_cache=None) -> None:
+                        kv_cache=None, rope=None) -> None:
         n0 = meta.num_prefill_tokens
         q, k, v = query[n0:], key[n0:], value[n0:]
         block_tables = dm.block_tables
@@ -815,8 +831,10 @@ class PagedEvictImpl(_ImplBase):
             step["launcher"] = launcher
         if (launcher is not None and launcher.tables is block_tables and launcher.zero is zero_slots
                 and kv_cache is not None and launcher.matches(q, k, v, kv_cache)):
-            launcher.run(q, k, v, kv_cache, out[n0:])
+            launcher.run(q, k, v, kv_cache, out[n0:], rope)
             return
+        if rope is not None and q.shape[0] > 0:
+            ops.rotary_embedding(rope[0], q, k, self.head_size, rope[1], rope[2])
         PagedAttention.write_to_paged_cache(k, v, key_cache, value_cache, dm.slot_mapping,
                                             self.kv_cache_dtype, 1.0, 1.0, zero_slots=zero_slots)
         PagedAttention.forward_decode(q, key_cache, value_cache, block_tables, seq_lens_arg,

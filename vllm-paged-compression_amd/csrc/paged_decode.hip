@@ -58,6 +58,15 @@ struct DecTile {
   typename Traits<T>::vec4 v[2][HEAD_SIZE / 16];
 };
 
+// Rotary-embedding inputs of pe_decode_step_rope
+struct RopeArgs {
+  const int64_t* positions;  // [num_seqs]
+  const void* cos_sin;       // [max_position, rot_dim], first half of a row cos, second half sin
+  int rot_dim;
+  int is_neox;
+  int64_t max_position;
+};
+
 // Partial results of one split: [split][seq][head] -> m, l, then O[D] (all f32)
 __host__ __device__ inline int64_t ws_stride(int head_size) { return head_size + 2; }
 
@@ -66,7 +75,13 @@ __host__ __device__ inline int64_t ws_stride(int head_size) { return head_size +
 // sequence spread over more waves of ONE workgroup, which merges them through LDS, instead of
 // over KV splits that need a second launch to be merged.  16 waves leave 128 registers per
 // wave, enough for one tile in flight.
-template <typename T, int HEAD_SIZE, int WAVES>
+//
+// ROPE: the rotary embedding of the step's query and key rows runs inside the launch
+// (pe_decode_step_rope).  The fragment layout keeps both elements of a rotation pair in one lane
+// (NeoX: element d and d + rot_dim/2 sit in k-steps ks and ks + rot_dim/64 of the same lane when
+// rot_dim is a multiple of 64; GPT-J: adjacent elements), so Q is rotated in registers right after
+// it is loaded and the new K row before it is used and stored; neither tensor is written back.
+template <typename T, int HEAD_SIZE, int WAVES, bool ROPE>
 __global__ __launch_bounds__(WAVES * 64, (WAVES >= 16 ? 4 : (HEAD_SIZE <= 128 ? PE_DEC_OCC : 2)))
 void paged_decode_mfma_kernel(
     T* __restrict__ out, float* __restrict__ ws, const T* __restrict__ query,
@@ -76,7 +91,9 @@ void paged_decode_mfma_kernel(
     int max_num_blocks_per_seq, int64_t q_stride, int64_t kv_block_stride,
     int64_t kv_head_stride, float scale, int num_splits, const T* __restrict__ new_key,
     const T* __restrict__ new_value, const int64_t* __restrict__ new_slots, int64_t new_k_stride,
-    int64_t new_v_stride, int64_t num_slots, T* key_cache_w, T* value_cache_w) {
+    int64_t new_v_stride, int64_t num_slots, T* key_cache_w, T* value_cache_w,
+    const int64_t* __restrict__ rope_positions, const T* __restrict__ rope_cos_sin, int rot_dim,
+    int rope_neox, int64_t rope_max_position) {
   // key_cache_w / value_cache_w: the same caches through non-restrict pointers, used only by
   // the fused KV write (the written slot is never loaded by this launch).
   using TR = Traits<T>;
@@ -147,6 +164,85 @@ void paged_decode_mfma_kernel(
       qf[ks] = __builtin_bit_cast(vec8, raw);
     }
   }
+  // Rotation of a row held as fragments (lane: elements 32*ks + 8g .. +8 of every k-step), with
+  // the arithmetic of the stand-alone kernel (rot_pair), so that the fused step is bit-identical
+  // to rotary embedding followed by pe_decode_step.  The cosines and sines of the lane's elements
+  // are requested here, in front of the first K/V tiles, and consumed once those are under way
+  // (the position -> cos/sin chain of dependent loads then runs beside the table -> K/V chain
+  // instead of in front of it).  NeoX, rot_dim = 64*hs: cs[ks] = cosines and cs[hs + ks] = sines
+  // of k-step ks < hs, which pairs with k-step ks + hs; GPT-J: cs[ks] = 4 cosines, 4 sines of the
+  // chunk's adjacent pairs.  The loops are unrolled over every hs the head size admits, so all
+  // fragment indices are constants.
+  auto rope_load = [&](u32x4 (&cs)[KS]) {
+    int64_t pos = rope_positions[seq];
+    pos = pos < 0 ? 0 : (pos >= rope_max_position ? rope_max_position - 1 : pos);
+    const T* cs_row = rope_cos_sin + pos * rot_dim;
+    const int half = rot_dim / 2;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) cs[ks] = u32x4{0u, 0u, 0u, 0u};
+    if (rope_neox) {
+#pragma unroll
+      for (int hs = 1; hs <= KS / 2; ++hs) {
+        if (rot_dim != 64 * hs) continue;
+#pragma unroll
+        for (int ks = 0; ks < hs; ++ks) {
+          cs[ks] = *reinterpret_cast<const u32x4*>(cs_row + 32 * ks + 8 * g);
+          cs[hs + ks] = *reinterpret_cast<const u32x4*>(cs_row + half + 32 * ks + 8 * g);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int d0 = 32 * ks + 8 * g;  // rot_dim is a multiple of 16: a chunk is rotated whole
+        if (d0 >= rot_dim) continue;
+        const u32x2 c4 = *reinterpret_cast<const u32x2*>(cs_row + d0 / 2);
+        const u32x2 s4 = *reinterpret_cast<const u32x2*>(cs_row + half + d0 / 2);
+        cs[ks] = u32x4{c4[0], c4[1], s4[0], s4[1]};
+      }
+    }
+  };
+  auto rope_apply = [&](vec8 (&f)[KS], const u32x4 (&cs)[KS]) {
+    if (rope_neox) {
+#pragma unroll
+      for (int hs = 1; hs <= KS / 2; ++hs) {
+        if (rot_dim != 64 * hs) continue;
+#pragma unroll
+        for (int ks = 0; ks < hs; ++ks) {
+          const vec8 c8 = __builtin_bit_cast(vec8, cs[ks]);
+          const vec8 s8 = __builtin_bit_cast(vec8, cs[hs + ks]);
+          vec8 x = f[ks], y = f[ks + hs];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            T ox, oy;
+            rot_pair<T>(to_f32(x[j]), to_f32(y[j]), to_f32(c8[j]), to_f32(s8[j]), ox, oy);
+            x[j] = ox;
+            y[j] = oy;
+          }
+          f[ks] = x;
+          f[ks + hs] = y;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        if (32 * ks + 8 * g >= rot_dim) continue;
+        const vec8 cs8 = __builtin_bit_cast(vec8, cs[ks]);  // [0..4) cosines, [4..8) sines
+        vec8 x = f[ks];
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+          T ox, oy;
+          rot_pair<T>(to_f32(x[j]), to_f32(x[j + 1]), to_f32(cs8[j / 2]), to_f32(cs8[4 + j / 2]), ox, oy);
+          x[j] = ox;
+          x[j + 1] = oy;
+        }
+        f[ks] = x;
+      }
+    }
+  };
+  static_assert(!ROPE || HEAD_SIZE <= 128, "the rotating form is built for head sizes 64 and 128");
+  u32x4 cs_q[KS];
+  bool q_rotated = !ROPE;
+  if constexpr (ROPE) rope_load(cs_q);
   const float slope =
       (alibi_slopes != nullptr && hc < gqa) ? alibi_slopes[kvh * gqa + hc] : 0.f;
 
@@ -251,6 +347,10 @@ void paged_decode_mfma_kernel(
     int p = pair_begin + wave;
     if (p < pair_end) {
       issue(t0, p);
+      if constexpr (ROPE) {
+        rope_apply(qf, cs_q);
+        q_rotated = true;
+      }
       while (true) {
         if (p + WAVES < pair_end) issue(t1, p + WAVES);
         compute(t0, 2 * p * BS, cached_len);
@@ -267,6 +367,12 @@ void paged_decode_mfma_kernel(
     DecTile<T, HEAD_SIZE> t0;
     for (int p = pair_begin + wave; p < pair_end; p += WAVES) {
       issue(t0, p);
+      if constexpr (ROPE) {
+        if (!q_rotated) {
+          rope_apply(qf, cs_q);
+          q_rotated = true;
+        }
+      }
       compute(t0, 2 * p * BS, cached_len);
     }
   }
@@ -277,6 +383,10 @@ void paged_decode_mfma_kernel(
     const T* ksrc = new_key + (int64_t)seq * new_k_stride + (int64_t)kvh * HEAD_SIZE;
     const T* vsrc = new_value + (int64_t)seq * new_v_stride + (int64_t)kvh * HEAD_SIZE;
     DecTile<T, HEAD_SIZE> tn;
+    // the new key row sits at the query's position: the same cosines and sines, requested again
+    // together with the row itself (they were not kept across the main loop)
+    u32x4 cs_n[KS];
+    if constexpr (ROPE) rope_load(cs_n);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       u32x4 raw = {0u, 0u, 0u, 0u};
@@ -291,15 +401,29 @@ void paged_decode_mfma_kernel(
       tn.v[0][dt] = v4;
       tn.v[1][dt] = vec4{(T)0.f, (T)0.f, (T)0.f, (T)0.f};
     }
+    if constexpr (ROPE) {
+      if (!q_rotated) rope_apply(qf, cs_n);  // a wave that had no block pair of its own
+      rope_apply(tn.k[0], cs_n);             // zero rows (hc != 0) stay zero
+    }
     compute(tn, seq_len - 1, seq_len);
     // store the row into its cache slot (same bytes pe_reshape_and_cache writes)
     const int64_t blk = new_slot / BS;
     const int off = (int)(new_slot % BS);
     T* kdst = key_cache_w + blk * kv_block_stride + (int64_t)kvh * kv_head_stride;
     T* vdst = value_cache_w + blk * kv_block_stride + (int64_t)kvh * kv_head_stride;
-    for (int c = lane; c < HEAD_SIZE / 8; c += 64)
-      *reinterpret_cast<u32x4*>(kdst + (c * BS + off) * 8) =
-          *reinterpret_cast<const u32x4*>(ksrc + c * 8);
+    if constexpr (ROPE) {
+      // the rotated row only exists in the fragments: lane (g, hc = 0) holds 16-byte chunk 4*ks + g
+      if (hc == 0) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+          *reinterpret_cast<u32x4*>(kdst + ((4 * ks + g) * BS + off) * 8) =
+              __builtin_bit_cast(u32x4, tn.k[0][ks]);
+      }
+    } else {
+      for (int c = lane; c < HEAD_SIZE / 8; c += 64)
+        *reinterpret_cast<u32x4*>(kdst + (c * BS + off) * 8) =
+            *reinterpret_cast<const u32x4*>(ksrc + c * 8);
+    }
     for (int d = lane; d < HEAD_SIZE; d += 64) vdst[d * BS + off] = vsrc[d];
   }
 
@@ -581,7 +705,8 @@ static int decode_impl(void* out, const void* query, const void* key_cache, cons
                        int64_t kv_block_stride, int64_t kv_head_stride, float scale, int max_seq_len,
                        int dtype, void* workspace, int64_t workspace_bytes, void* stream,
                        const void* new_key, const void* new_value, const int64_t* new_slots,
-                       int64_t new_k_stride, int64_t new_v_stride, int64_t num_slots) {
+                       int64_t new_k_stride, int64_t new_v_stride, int64_t num_slots,
+                       const pe::RopeArgs* rope = nullptr) {
   using namespace pe;
   PE_REQUIRE(num_seqs >= 0, PE_ERR_INVALID_ARG, "negative num_seqs");
   if (num_seqs == 0) return PE_OK;
@@ -604,6 +729,7 @@ static int decode_impl(void* out, const void* query, const void* key_cache, cons
                    kv_block_stride, kv_head_stride)) {
     int splits = 1, waves = DEC_WAVES;
     choose_shape(num_seqs, num_heads, num_kv_heads, head_size, max_seq_len, &waves, &splits);
+    if (rope != nullptr && waves > 8) waves = 8;  // the rotating form is built for 4 and 8 waves
     float* ws = static_cast<float*>(workspace);
     if (splits > 1) {
       const int64_t need = (int64_t)splits * num_seqs * num_heads * ws_stride(head_size) * 4;
@@ -613,19 +739,30 @@ static int decode_impl(void* out, const void* query, const void* key_cache, cons
     }
     dim3 grid((unsigned)splits, (unsigned)num_kv_heads, (unsigned)num_seqs);
     const size_t lds = merge_lds_bytes(waves, num_heads / num_kv_heads, head_size);
-#define PE_LAUNCH_DEC_W(T, HS, W)                                                                \
-  if (lds > 64 * 1024)                                                                           \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&paged_decode_mfma_kernel<T, HS, W>), \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);             \
-  hipLaunchKernelGGL((paged_decode_mfma_kernel<T, HS, W>), grid, dim3(W * 64), lds, st, (T*)out, \
-                     ws, (const T*)query, (const T*)key_cache, (const T*)value_cache,            \
-                     block_tables, seq_lens, alibi_slopes, num_heads, num_kv_heads,              \
-                     max_num_blocks_per_seq, q_stride, kv_block_stride, kv_head_stride, scale,   \
-                     splits, (const T*)new_key, (const T*)new_value, new_slots, new_k_stride,     \
-                     new_v_stride, num_slots, (T*)key_cache, (T*)value_cache)
+#define PE_LAUNCH_DEC_WR(T, HS, W, R)                                                              \
+  if (lds > 64 * 1024)                                                                             \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&paged_decode_mfma_kernel<T, HS, W, R>), \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);               \
+  hipLaunchKernelGGL((paged_decode_mfma_kernel<T, HS, W, R>), grid, dim3(W * 64), lds, st, (T*)out, \
+                     ws, (const T*)query, (const T*)key_cache, (const T*)value_cache,              \
+                     block_tables, seq_lens, alibi_slopes, num_heads, num_kv_heads,                \
+                     max_num_blocks_per_seq, q_stride, kv_block_stride, kv_head_stride, scale,     \
+                     splits, (const T*)new_key, (const T*)new_value, new_slots, new_k_stride,       \
+                     new_v_stride, num_slots, (T*)key_cache, (T*)value_cache,                      \
+                     R ? rope->positions : nullptr, R ? (const T*)rope->cos_sin : nullptr,         \
+                     R ? rope->rot_dim : 0, R ? rope->is_neox : 0, R ? rope->max_position : 0)
+#define PE_LAUNCH_DEC_W(T, HS, W) PE_LAUNCH_DEC_WR(T, HS, W, false)
 #define PE_LAUNCH_DEC(T, HS)                               \
   do {                                                     \
-    if (waves == 16) {                                     \
+    if (rope != nullptr) {                                 \
+      if constexpr (HS <= 128) {                           \
+        if (waves == 8) {                                  \
+          PE_LAUNCH_DEC_WR(T, HS, 8, true);                \
+        } else {                                           \
+          PE_LAUNCH_DEC_WR(T, HS, DEC_WAVES, true);        \
+        }                                                  \
+      }                                                    \
+    } else if (waves == 16) {                              \
       PE_LAUNCH_DEC_W(T, HS, 16);                          \
     } else if (waves == 8) {                               \
       PE_LAUNCH_DEC_W(T, HS, 8);                           \
@@ -640,6 +777,7 @@ static int decode_impl(void* out, const void* query, const void* key_cache, cons
     });
 #undef PE_LAUNCH_DEC
 #undef PE_LAUNCH_DEC_W
+#undef PE_LAUNCH_DEC_WR
     if (int rc = check_launch("paged_decode")) return rc;
     if (splits > 1) {
 #define PE_LAUNCH_MERGE(T, MS)                                                                   \
@@ -728,6 +866,47 @@ int pe_decode_step(void* out, const void* query, const void* new_key, const void
                      slot_mapping, new_k_stride, new_v_stride, num_blocks * block_size);
 }
 
+int pe_decode_step_rope(void* out, const void* query, const void* new_key, const void* new_value,
+                        void* key_cache, void* value_cache, const int64_t* slot_mapping,
+                        const int32_t* block_tables, const int32_t* seq_lens,
+                        const float* alibi_slopes, const int64_t* positions,
+                        const void* cos_sin_cache, int rot_dim, int is_neox, int64_t max_position,
+                        int num_seqs, int num_heads, int num_kv_heads, int head_size,
+                        int block_size, int64_t num_blocks, int max_num_blocks_per_seq,
+                        int64_t q_stride, int64_t new_k_stride, int64_t new_v_stride,
+                        int64_t kv_block_stride, int64_t kv_head_stride, float scale,
+                        int max_seq_len, int dtype, void* workspace, int64_t workspace_bytes,
+                        void* stream) {
+  using namespace pe;
+  PE_REQUIRE(num_seqs == 0 || (new_key && new_value && slot_mapping && positions && cos_sin_cache),
+             PE_ERR_INVALID_ARG, "decode_step_rope: null pointer");
+  PE_REQUIRE(new_k_stride % 8 == 0 && new_v_stride % 8 == 0 &&
+                 (((uintptr_t)new_key | (uintptr_t)new_value | (uintptr_t)cos_sin_cache) % 16 == 0),
+             PE_ERR_INVALID_ARG, "decode_step_rope: rows must be 16-byte aligned");
+  PE_REQUIRE(num_blocks > 0 && max_position > 0, PE_ERR_INVALID_ARG,
+             "decode_step_rope: bad num_blocks / max_position");
+  PE_REQUIRE(mfma_path_ok(num_heads, num_kv_heads, head_size, block_size, dtype, q_stride,
+                          kv_block_stride, kv_head_stride),
+             PE_ERR_UNSUPPORTED,
+             "decode_step_rope needs the MFMA decode path (16-bit dtype, block_size 16, head_size "
+             "64/128, strides multiples of 8): use pe_rope_reshape_and_cache + pe_paged_decode");
+  PE_REQUIRE(head_size <= 128, PE_ERR_UNSUPPORTED,
+             "decode_step_rope: head_size %d has no registers left for the rotation; use "
+             "pe_rope_reshape_and_cache + pe_paged_decode", head_size);
+  // both elements of a rotation pair must sit in one lane of the fragment layout
+  PE_REQUIRE(rot_dim > 0 && rot_dim <= head_size &&
+                 (is_neox ? rot_dim % 64 == 0 : rot_dim % 16 == 0),
+             PE_ERR_UNSUPPORTED,
+             "decode_step_rope: rot_dim %d (head_size %d) must be a multiple of %d; use "
+             "pe_rope_reshape_and_cache + pe_paged_decode",
+             rot_dim, head_size, is_neox ? 64 : 16);
+  const RopeArgs rope{positions, cos_sin_cache, rot_dim, is_neox ? 1 : 0, max_position};
+  return decode_impl(out, query, key_cache, value_cache, block_tables, seq_lens, alibi_slopes,
+                     num_seqs, num_heads, num_kv_heads, head_size, block_size,
+                     max_num_blocks_per_seq, q_stride, kv_block_stride, kv_head_stride, scale,
+                     max_seq_len, dtype, workspace, workspace_bytes, stream, new_key, new_value,
+                     slot_mapping, new_k_stride, new_v_stride, num_blocks * block_size, &rope);
+}
 
 // ---------------------------------------------------------------------------------------
 // pe_paged_decode_noalloc: the split-KV partials live in a file-scope device array instead of a

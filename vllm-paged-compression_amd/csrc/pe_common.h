@@ -107,6 +107,19 @@ __device__ __forceinline__ float round_to_strict(float v) {
   return round_to<T>(v);
 }
 
+// One rotary-embedding pair in the storage type's arithmetic, as the reference kernel computes it
+// (csrc/pos_encoding_kernels.cu:10-35): x*cos, y*sin, y*cos and x*sin are each rounded to T, and so
+// are their difference and sum (separate multiplies and add/sub, no contraction).
+template <typename T>
+__device__ __forceinline__ void rot_pair(float x, float y, float c, float s, T& ox, T& oy) {
+  const float xc = round_to_strict<T>(x * c);
+  const float ys = round_to_strict<T>(y * s);
+  const float yc = round_to_strict<T>(y * c);
+  const float xs = round_to_strict<T>(x * s);
+  ox = from_f32<T>(xc - ys);
+  oy = from_f32<T>(yc + xs);
+}
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m));

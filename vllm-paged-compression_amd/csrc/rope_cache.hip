@@ -16,17 +16,6 @@ constexpr int RP_TOKENS = 16;   // tokens per workgroup tile
 constexpr int RP_THREADS = 256;
 
 template <typename T>
-__device__ __forceinline__ void rot_pair(float x, float y, float c, float s, T& ox, T& oy) {
-  // separate multiplies and add/sub (no contraction), each rounded to T
-  const float xc = round_to_strict<T>(x * c);
-  const float ys = round_to_strict<T>(y * s);
-  const float yc = round_to_strict<T>(y * c);
-  const float xs = round_to_strict<T>(x * s);
-  ox = from_f32<T>(xc - ys);
-  oy = from_f32<T>(yc + xs);
-}
-
-template <typename T>
 union Chunk {
   u32x4 v;
   T e[16 / sizeof(T)];

@@ -709,6 +709,59 @@ def decode_step(out, query, key, value, key_cache, value_cache, slot_mapping, nu
         0 if ws is None else ws.numel(), _stream(dev)), "decode_step")
 
 
+def decode_step_rope(out, positions, query, key, value, key_cache, value_cache, slot_mapping,
+                     num_kv_heads, scale, block_tables, seq_lens, block_size, max_seq_len,
+                     cos_sin_cache, is_neox, alibi_slopes=None) -> None:
+    """Rotary embedding of the step's query/key rows + KV write + paged attention in ONE launch
+    (see pe_decode_step_rope): what ``rotary_embedding`` followed by ``decode_step`` computes,
+    except that ``query`` and ``key`` are given unrotated and stay as they are.  positions int64
+    [S], cos_sin_cache [max_position, rot_dim] of the query dtype."""
+    dev = _need_gpu(out, positions, query, key, value, key_cache, value_cache, slot_mapping,
+                    block_tables, seq_lens, cos_sin_cache)
+    S, Hq, D = query.shape
+    nb = value_cache.shape[0]
+    if key.shape != (S, num_kv_heads, D) or value.shape != key.shape:
+        raise RuntimeError("decode_step_rope: key/value must be [num_seqs, num_kv_heads, head_size]")
+    for t in (query, key, value):
+        if t.stride(2) != 1 or t.stride(1) != D or t.dtype != key_cache.dtype:
+            raise RuntimeError("decode_step_rope: dense rows of the cache dtype expected")
+    if slot_mapping.dtype != torch.int64 or slot_mapping.numel() != S or not slot_mapping.is_contiguous():
+        raise RuntimeError("decode_step_rope: slot_mapping must be contiguous int64[num_seqs]")
+    if positions.dtype != torch.int64 or positions.numel() != S or not positions.is_contiguous():
+        raise RuntimeError("decode_step_rope: positions must be contiguous int64[num_seqs]")
+    if cos_sin_cache.dim() != 2 or not cos_sin_cache.is_contiguous() or cos_sin_cache.dtype != query.dtype:
+        raise RuntimeError("decode_step_rope: cos_sin_cache [max_position, rot_dim] of the query dtype expected")
+    if block_tables.dtype != torch.int32 or seq_lens.dtype != torch.int32 or \
+            not block_tables.is_contiguous() or not seq_lens.is_contiguous() or not out.is_contiguous():
+        raise RuntimeError("decode_step_rope: int32 contiguous block_tables/seq_lens, contiguous out expected")
+    lib = _lib.load()
+    rot_dim = cos_sin_cache.shape[1]
+    if not decode_step_rope_supported(Hq, num_kv_heads, D, block_size, query.dtype, rot_dim, is_neox):
+        raise RuntimeError("decode_step_rope: shape or rot_dim not supported by the fused kernel; use "
+                           "rotary_embedding_and_cache + paged_attention_v1")
+    need = lib.pe_paged_decode_workspace_bytes(S, Hq, num_kv_heads, D, block_size, max_seq_len)
+    ws = _workspace(dev, need)
+    _lib.check(lib.pe_decode_step_rope(
+        _p(out), _p(query), _p(key), _p(value), _p(key_cache), _p(value_cache), _p(slot_mapping),
+        _p(block_tables), _p(seq_lens), _p(alibi_slopes), _p(positions), _p(cos_sin_cache), rot_dim,
+        1 if is_neox else 0, cos_sin_cache.shape[0], S, Hq, num_kv_heads, D, block_size, nb,
+        block_tables.shape[1], query.stride(0), key.stride(0), value.stride(0), key_cache.stride(0),
+        key_cache.stride(1), float(scale), int(max_seq_len), _dtype_code(query), _p(ws),
+        0 if ws is None else ws.numel(), _stream(dev)), "decode_step_rope")
+
+
+def decode_step_rope_supported(num_heads: int, num_kv_heads: int, head_size: int, block_size: int,
+                               dtype: torch.dtype, rot_dim: int, is_neox: bool) -> bool:
+    """Whether ``decode_step_rope`` serves this geometry (otherwise: the separate launches)."""
+    if dtype not in (torch.bfloat16, torch.float16):
+        return False
+    lib = _lib.load()
+    code = _lib.PE_BF16 if dtype == torch.bfloat16 else _lib.PE_F16
+    if not lib.pe_paged_decode_supports_fused_write(num_heads, num_kv_heads, head_size, block_size, code):
+        return False
+    return head_size <= 128 and 0 < rot_dim <= head_size and rot_dim % (64 if is_neox else 16) == 0
+
+
 # --------------------------------------------------------------------------------------
 def _prewrap(fn, first: int, tail: tuple) -> tuple:
     """``tail`` (arguments ``first``.. of ``fn``) as instances of the declared C types."""
@@ -773,6 +826,11 @@ class DecodeLayerLauncher:
                          stream)
         # constant arguments converted to their C types once: the per-layer foreign call then
         # converts only the six tensor pointers
+        # the rotating form takes the same arguments with (positions, cos_sin_cache, rot_dim,
+        # is_neox, max_position) after alibi_slopes
+        self._fr_head = _prewrap(lib.pe_decode_step_rope, 6, self._fs_tail[:4])
+        self._fr_rest = _prewrap(lib.pe_decode_step_rope, 15, self._fs_tail[4:])
+        self._rope_geom = (num_heads, num_kv_heads, head_size, bs, S)
         self._rc_tail = _prewrap(lib.pe_reshape_and_cache, 4, self._rc_tail)
         self._pa_tail = _prewrap(lib.pe_paged_decode, 4, self._pa_tail)
         self._fs_tail = _prewrap(lib.pe_decode_step, 6, self._fs_tail)
@@ -791,7 +849,11 @@ class DecodeLayerLauncher:
     # the launch stream and appends (start, end)
     event_sink = None
 
-    def run(self, query, key, value, kv_cache, out) -> None:
+    def run(self, query, key, value, kv_cache, out, rope=None) -> None:
+        """``rope`` = (positions int64 [S], cos_sin_cache [max_position, rot_dim], is_neox): the
+        layer's query/key rows arrive unrotated.  On the one-launch path the rotation runs inside
+        the attention kernel and query/key stay as they are; otherwise they are rotated in place
+        first, as the reference's rotary_embedding does."""
         # the kernels write a dense [S, Hq, D] tensor of the cache dtype at out's address
         if out.numel() != self._out_numel or out.dtype != self._out_dtype or not out.is_contiguous():
             raise RuntimeError("decode launcher: output must be a contiguous tensor of "
@@ -800,6 +862,21 @@ class DecodeLayerLauncher:
         vc = kc + self.v_off
         lib = self._lib
         sink = DecodeLayerLauncher.event_sink
+        if rope is not None:
+            positions, cos_sin, is_neox = rope
+            Hq, Hkv, D, bs, S = self._rope_geom
+            if positions.dtype != torch.int64 or positions.numel() != S or not positions.is_contiguous() \
+                    or cos_sin.dim() != 2 or cos_sin.dtype != self._out_dtype or not cos_sin.is_contiguous():
+                raise RuntimeError("decode launcher: positions int64 [num_seqs] and cos_sin_cache "
+                                   "[max_position, rot_dim] of the cache dtype expected")
+            if self.fused and sink is None and decode_step_rope_supported(
+                    Hq, Hkv, D, bs, self._out_dtype, cos_sin.shape[1], is_neox):
+                _lib.check(lib.pe_decode_step_rope(
+                    out.data_ptr(), query.data_ptr(), key.data_ptr(), value.data_ptr(), kc, vc,
+                    *self._fr_head, positions.data_ptr(), cos_sin.data_ptr(), cos_sin.shape[1],
+                    1 if is_neox else 0, cos_sin.shape[0], *self._fr_rest), "decode_step_rope")
+                return
+            rotary_embedding(positions, query, key, D, cos_sin, is_neox)
         if self.fused:
             if sink is not None:
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
