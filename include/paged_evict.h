@@ -167,7 +167,12 @@ int pe_paged_decode(void* out, const void* query, const void* key_cache,
  *     gets the compacted table and the length shortened by one block: the step's token is the
  *     last token of the sequence's last block in both views).  The kernel does not check it: a
  *     slot that is inconsistent with the table leaves this step's output correct and the cache
- *     wrong for later steps.
+ *     wrong for later steps;
+ *   - a block that receives a new token in this call must not appear in another sequence's
+ *     table: that sequence's workgroups read the block while the row is being stored, so its
+ *     output would depend on timing.  A block manager never builds such tables (a block shared
+ *     by two sequences is copied before either writes into it, pe_copy_blocks); with
+ *     pe_reshape_and_cache + pe_paged_decode the write is complete before any read.
  * A negative slot (padding) or one beyond num_blocks*block_size skips the fusion for that
  * sequence: nothing is stored and all seq_lens[s] positions are read from the cache, as
  * pe_paged_decode does.  A shape or stride the fused kernel cannot serve returns
