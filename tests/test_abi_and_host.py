@@ -63,6 +63,29 @@ def test_argument_checks_without_gpu():
     rc = lib.pe_decode_step(p, p, p, p, p, p, p, p, p, None, 1, 32, 8, 128, 8, 4, 4, 4096, 1024, 1024,
                             8192, 1024, 0.1, 32, 2, None, 0, None)
     assert rc == 2 and b"fused KV write" in lib.pe_last_error()
+    # the rotating decode step refuses, before touching the device, what its fragment layout
+    # cannot rotate in one lane (NeoX pairing with rot_dim not a multiple of 64), head size 256
+    # and shapes outside the MFMA path; the Python-side predicate says the same beforehand
+    import vllm_paged_compression_amd.ops as ops
+
+    def step_rope(head, block, rot, neox):
+        return lib.pe_decode_step_rope(p, p, p, p, p, p, p, p, p, None, p, p, rot, neox, 4096, 1, 32, 8,
+                                       head, block, 4, 4, 4096, 1024, 1024, 8192, 1024, 0.1, 32, 2, None,
+                                       0, None)
+    assert step_rope(128, 16, 48, 1) == 2 and b"rot_dim 48" in lib.pe_last_error()
+    assert step_rope(256, 16, 128, 1) == 2 and b"head_size 256" in lib.pe_last_error()
+    assert step_rope(128, 8, 128, 1) == 2 and b"MFMA decode path" in lib.pe_last_error()
+    assert lib.pe_decode_step_rope(p, p, p, p, p, p, p, p, p, None, None, p, 128, 1, 4096, 1, 32, 8, 128,
+                                   16, 4, 4, 4096, 1024, 1024, 8192, 1024, 0.1, 32, 2, None, 0,
+                                   None) == 1 and b"null pointer" in lib.pe_last_error()
+    bf = torch.bfloat16
+    assert ops.decode_step_rope_supported(32, 8, 128, 16, bf, 128, True)
+    assert ops.decode_step_rope_supported(32, 8, 128, 16, bf, 64, True)
+    assert ops.decode_step_rope_supported(32, 8, 128, 16, bf, 48, False)
+    assert not ops.decode_step_rope_supported(32, 8, 128, 16, bf, 48, True)
+    assert not ops.decode_step_rope_supported(32, 8, 256, 16, bf, 128, True)
+    assert not ops.decode_step_rope_supported(32, 8, 128, 8, bf, 128, True)
+    assert not ops.decode_step_rope_supported(32, 8, 128, 16, torch.float32, 128, True)
 
 
 def test_ops_reject_cpu_tensors():

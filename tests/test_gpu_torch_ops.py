@@ -40,6 +40,11 @@ def test_schemas_match_reference(pe_ops):
                                                "slot_mapping", "kv_cache_dtype", "k_scale", "v_scale"]
     assert names(pe_ops.copy_blocks) == ["key_caches", "value_caches", "block_mapping"]
     assert names(pe_ops.swap_blocks) == ["src", "dst", "block_mapping"]
+    assert names(pe_ops.rotary_embedding) == ["positions", "query", "key", "head_size", "cos_sin_cache",
+                                              "is_neox"]
+    ro = pe_ops.rotary_embedding.default._schema
+    assert [a.alias_info is not None and a.alias_info.is_write for a in ro.arguments[:3]] == \
+        [False, True, True]
     sch = pe_ops.paged_attention_v1.default._schema
     assert sch.arguments[0].alias_info is not None and sch.arguments[0].alias_info.is_write
     assert str(sch.arguments[10].type) == "Optional[Tensor]"
@@ -125,6 +130,22 @@ def test_registered_cache_ops(oracle, pe_ops):
     assert torch.equal(back[0][20].cpu(), kv_host[0][0]) and torch.equal(back[1][1].cpu(), kv_host[1][6])
     with pytest.raises(RuntimeError, match="block_mapping must be on CPU"):
         pe_ops.swap_blocks(kv_dev[0], back[0], out_map.cuda())
+
+
+@pytest.mark.parametrize("is_neox", [True, False])
+def test_registered_rotary_embedding(oracle, pe_ops, is_neox):
+    """torch.ops.paged_evict.rotary_embedding rotates query and key in place as the oracle does."""
+    from test_oracle_golden import rope_cache
+    g = torch.Generator().manual_seed(11)
+    T, Hq, Hkv, D = 37, 8, 2, 128
+    cs = rope_cache(512, D, torch.bfloat16)
+    pos = torch.randint(0, 512, (T,), generator=g)
+    q = (torch.rand(T, Hq * D, generator=g) * 2 - 1).to(torch.bfloat16)
+    k = (torch.rand(T, Hkv * D, generator=g) * 2 - 1).to(torch.bfloat16)
+    qd, kd = q.cuda(), k.cuda()
+    pe_ops.rotary_embedding(pos.cuda(), qd, kd, D, cs.cuda(), is_neox)
+    assert torch.equal(qd.cpu(), oracle.rotary_embedding(pos, q, D, cs, is_neox))
+    assert torch.equal(kd.cpu(), oracle.rotary_embedding(pos, k, D, cs, is_neox))
 
 
 def test_selector_hook_and_backend_statics():

@@ -831,6 +831,7 @@ class DecodeLayerLauncher:
         self._fr_head = _prewrap(lib.pe_decode_step_rope, 6, self._fs_tail[:4])
         self._fr_rest = _prewrap(lib.pe_decode_step_rope, 15, self._fs_tail[4:])
         self._rope_geom = (num_heads, num_kv_heads, head_size, bs, S)
+        self._rope_ok = {}   # (rot_dim, is_neox) -> whether the rotating launch serves it
         self._rc_tail = _prewrap(lib.pe_reshape_and_cache, 4, self._rc_tail)
         self._pa_tail = _prewrap(lib.pe_paged_decode, 4, self._pa_tail)
         self._fs_tail = _prewrap(lib.pe_decode_step, 6, self._fs_tail)
@@ -869,12 +870,22 @@ class DecodeLayerLauncher:
                     or cos_sin.dim() != 2 or cos_sin.dtype != self._out_dtype or not cos_sin.is_contiguous():
                 raise RuntimeError("decode launcher: positions int64 [num_seqs] and cos_sin_cache "
                                    "[max_position, rot_dim] of the cache dtype expected")
-            if self.fused and sink is None and decode_step_rope_supported(
-                    Hq, Hkv, D, bs, self._out_dtype, cos_sin.shape[1], is_neox):
+            rot_key = (cos_sin.shape[1], bool(is_neox))
+            in_launch = self._rope_ok.get(rot_key)
+            if in_launch is None:
+                in_launch = self._rope_ok[rot_key] = decode_step_rope_supported(
+                    Hq, Hkv, D, bs, self._out_dtype, cos_sin.shape[1], is_neox)
+            if self.fused and in_launch:
+                if sink is not None:
+                    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    s.record()
                 _lib.check(lib.pe_decode_step_rope(
                     out.data_ptr(), query.data_ptr(), key.data_ptr(), value.data_ptr(), kc, vc,
                     *self._fr_head, positions.data_ptr(), cos_sin.data_ptr(), cos_sin.shape[1],
                     1 if is_neox else 0, cos_sin.shape[0], *self._fr_rest), "decode_step_rope")
+                if sink is not None:
+                    e.record()
+                    sink.append((s, e))
                 return
             rotary_embedding(positions, query, key, D, cos_sin, is_neox)
         if self.fused:
@@ -931,6 +942,10 @@ def register_torch_ops() -> None:
     lib.define("copy_blocks(Tensor(a!)[] key_caches, Tensor[](b!) value_caches,"
                " Tensor block_mapping) -> ()")
     lib.define("swap_blocks(Tensor src, Tensor! dst, Tensor block_mapping) -> ()")
+    # the step in front of the path (csrc/torch_bindings.cpp:141-145)
+    lib.define("rotary_embedding(Tensor positions, Tensor! query, Tensor! key, int head_size,"
+               " Tensor cos_sin_cache, bool is_neox) -> ()")
+    lib.impl("rotary_embedding", rotary_embedding, "CUDA")
     lib.impl("paged_attention_v1", paged_attention_v1, "CUDA")
     lib.impl("paged_attention_v2", paged_attention_v2, "CUDA")
     lib.impl("reshape_and_cache", lambda k, v, kc, vc, sm, dt, ks, vs: reshape_and_cache(
