@@ -1,0 +1,266 @@
+"""Golden decode-time eviction decisions, produced by running the *reference's own methods*.
+
+The backend module ``vllm/attention/backends/torch_cuda_sdpa.py`` cannot be imported in the build
+container (its package imports need ``msgspec``), but the four methods that take the decode
+decision only touch torch / numpy / random and a handful of attributes of ``self``:
+
+    TorchCUDASDPABackendImpl._prune_decode_reqs_streamingLLM   (:1375-1433)
+    TorchCUDASDPABackendImpl._prune_decode_reqs_inverseKeyL2   (:1435-1475)
+    TorchCUDASDPABackendImpl._prune_decode_reqs_topk           (:1478-1560)
+    TorchCUDASDPABackendImpl._create_updated_block_tables      (:1562-1586)
+
+``host_logic()`` does the same for three pieces of host arithmetic (admission size of a pruned
+prompt, slot mapping, kv-length adjustment on eviction steps).
+
+This script reads the file from the reference checkout at generation time, compiles exactly those
+function definitions (located with ``ast``; nothing of the file is stored), binds them to a
+stand-in ``self`` that carries the reference's real ``KVCachePruner`` and ``BlockL2NormManager``
+(both importable as they are), and drives them through multi-step decode traces the way the engine
+does (layer 0's victims are committed to the tables, ``llm_engine.py:1179-1193``).  Only data is
+written: per step the inputs (logical lengths, block tables) and what the methods returned
+(victims, the compacted table tensor, zeroed slots, the score lists afterwards).
+
+Run:  python tests/golden/make_golden_decode.py  [--reference /root/reference]
+"""
+import argparse
+import ast
+import importlib.util
+import json
+import os
+import random
+import textwrap
+import types
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+METHODS = ("_prune_decode_reqs_streamingLLM", "_prune_decode_reqs_inverseKeyL2",
+           "_prune_decode_reqs_topk", "_create_updated_block_tables")
+
+
+def load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def reference_methods(path):
+    """The four method definitions of the impl class, compiled from the reference file."""
+    src = open(path).read()
+    tree = ast.parse(src)
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "TorchCUDASDPABackendImpl")
+    ns = {"torch": torch, "np": np, "random": random, "TorchCUDASDPAMetadata": object}
+    for node in cls.body:
+        if isinstance(node, ast.FunctionDef) and node.name in METHODS:
+            exec(compile(textwrap.dedent(ast.get_source_segment(src, node)), path, "exec"), ns)
+    return {m: ns[m] for m in METHODS}
+
+
+def reference_function(path, name, cls_name=None, extra=None):
+    """One function (or method of ``cls_name``) compiled from a reference file."""
+    src = open(path).read()
+    body = ast.parse(src).body
+    if cls_name is not None:
+        body = next(n for n in body if isinstance(n, ast.ClassDef) and n.name == cls_name).body
+    node = next(n for n in body if isinstance(n, ast.FunctionDef) and n.name == name)
+    ns = dict(extra or {})
+    exec(compile(textwrap.dedent(ast.get_source_segment(src, node)), path, "exec"), ns)
+    return ns[name]
+
+
+def host_logic(ref):
+    """Host-side integer arithmetic of the path, from the reference's own functions:
+    get_num_required_blocks_after_prune_promt (vllm/core/page_evict_kv_util.py:6-36),
+    TorchCUDASDPAMetadataBuilder._compute_slot_mapping (torch_cuda_sdpa.py:565-598) and the
+    kv-length adjustment of ModelInputForGPUBuilder._compute_lens (vllm/worker/model_runner.py:493-558)."""
+    import math
+    from typing import List
+    out = {}
+    req = reference_function(f"{ref}/vllm/core/page_evict_kv_util.py",
+                             "get_num_required_blocks_after_prune_promt",
+                             extra={"math": math, "cdiv": lambda a, b: -(a // -b), "PagedEvictConfig": object})
+    rows = []
+    for bs in (8, 16, 32):
+        for budget in (3 * bs, 4 * bs, 128, 512, 768, 4096):
+            if budget < 3 * bs or budget % bs:
+                continue
+            for method in ("streamingLLM", "streamingLLM-1", "inverse_key_l2", "local", "global"):
+                cfg = SimpleNamespace(cache_budget=budget, initial_blocks=1, evict_method=method,
+                                      cache_prune_type="budget")
+                for L in (1, bs, budget - 1, budget, budget + 1, budget + bs, budget + bs + 3, 1024, 1030,
+                          2 * budget + 5, 8192, 32768):
+                    nblk, ntok = req(L, cfg, bs)
+                    rows.append([bs, budget, method, L, int(nblk), int(ntok)])
+    out["required_blocks"] = rows
+
+    slot = reference_function(f"{ref}/vllm/attention/backends/torch_cuda_sdpa.py", "_compute_slot_mapping",
+                              "TorchCUDASDPAMetadataBuilder", extra={"List": List, "PAD_SLOT_ID": -1})
+    me = SimpleNamespace(sliding_window=None)
+    rng = random.Random(7)
+    cases = []
+    for bs in (8, 16):
+        for kept in (1, bs - 1, bs, bs + 1, 5 * bs, 5 * bs + 3, 48 * bs, 48 * bs + 7):
+            table = rng.sample(range(1000), -(-kept // bs))
+            sm = []
+            slot(me, False, True, sm, 4, kept, 0, bs, {4: table})
+            cases.append({"prompt": True, "bs": bs, "query_len": kept, "context_len": 0, "table": table,
+                          "slots": sm})
+        for ctx in (0, 1, bs - 1, bs, bs + 5, 47 * bs + 15, 48 * bs):
+            table = rng.sample(range(1000), ctx // bs + 1)
+            sm = []
+            slot(me, False, False, sm, 9, 1, ctx, bs, {9: table})
+            cases.append({"prompt": False, "bs": bs, "query_len": 1, "context_len": ctx, "table": table,
+                          "slots": sm})
+    sm = []
+    slot(me, True, True, sm, 0, 5, 0, 16, {0: [3]})
+    cases.append({"prompt": True, "profile": True, "bs": 16, "query_len": 5, "context_len": 0, "table": [3],
+                  "slots": sm})
+    out["slot_mapping"] = cases
+
+    lens_fn = reference_function(f"{ref}/vllm/worker/model_runner.py", "_compute_lens", "ModelInputForGPUBuilder",
+                                 extra={"InterDataForSeqGroup": object, "SequenceGroupMetadata": object})
+    rows = []
+    for method in ("streamingLLM", "streamingLLM-1", "global", "local", "inverse_key_l2"):
+        for bs, budget in ((16, 64), (16, 768), (8, 48)):
+            cfg = SimpleNamespace(evict_method=method, cache_budget=budget)
+            runner = SimpleNamespace(scheduler_config=SimpleNamespace(is_multi_step=False),
+                                     model_config=SimpleNamespace(is_encoder_decoder=False),
+                                     cache_config=SimpleNamespace(paged_evict_config=cfg, block_size=bs))
+            for seq_len in (budget - 1, budget, budget + 1, budget + bs - 1, budget + bs, budget + bs + 1,
+                            budget + 2 * bs, budget + 5 * bs, 2 * budget + 3):
+                kv_before = min(seq_len, budget + bs)
+                seq_data = SimpleNamespace(get_len=lambda n=seq_len: n,
+                                           get_num_computed_tokens=lambda n=seq_len: n - 1,
+                                           get_token_ids=lambda n=seq_len: list(range(n)),
+                                           mrope_position_delta=None)
+                sgm = SimpleNamespace(seq_data={5: seq_data}, token_chunk_size=1, token_type_ids=None)
+                inter = SimpleNamespace(seq_ids=[5], is_prompt=False, seq_lens=[0], orig_seq_lens=[0],
+                                        context_lens=[0], input_tokens=[[]], input_positions=[[]],
+                                        token_types=[[]], query_lens=[0], seq_kv_lens={5: kv_before},
+                                        mrope_input_positions=None, n_seqs=1)
+                lens_fn(SimpleNamespace(runner=runner), inter, 0, sgm)
+                rows.append([method, bs, budget, seq_len, kv_before, inter.seq_kv_lens[5], inter.query_lens[0],
+                             inter.context_lens[0], inter.input_positions[0][0]])
+    out["kv_len_adjust"] = rows
+    with open(os.path.join(HERE, "host_logic.json"), "w") as f:
+        json.dump(out, f)
+    print(f"host_logic: {len(out['required_blocks'])} admission rows, {len(out['slot_mapping'])} slot "
+          f"mappings, {len(out['kv_len_adjust'])} kv-length rows")
+
+
+def bits(t):
+    return t.contiguous().view(torch.int16).numpy().view(np.uint16).copy()
+
+
+def pad_tables(tables, width):
+    out = torch.zeros((len(tables), width), dtype=torch.int32)
+    for i, t in enumerate(tables):
+        out[i, :len(t)] = torch.tensor(t, dtype=torch.int32)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reference", default="/root/reference")
+    ref = ap.parse_args().reference
+    fns = reference_methods(f"{ref}/vllm/attention/backends/torch_cuda_sdpa.py")
+    kp = load("ref_kvcache_prunner", f"{ref}/vllm/attention/kvcache_prunner.py")
+    bm = load("ref_block_l2norm_manager", f"{ref}/vllm/attention/block_l2norm_manager.py")
+
+    bs, Hkv, D, nb = 16, 2, 32, 40
+    budget, topk, n_steps = 64, 3, 40
+    g = torch.Generator().manual_seed(4242)
+    kv_cache = (torch.rand(2, nb, bs * Hkv * D, generator=g) * 2 - 1).to(torch.bfloat16)
+    arrays = {"kv_cache": bits(kv_cache)}
+    meta = {"block_size": bs, "num_kv_heads": Hkv, "head_size": D, "num_blocks": nb, "budget": budget,
+            "topk_blocks": topk, "traces": []}
+
+    cases = [("streamingLLM", None, False), ("streamingLLM-1", None, False),
+             ("local", "value_l2", False), ("global", "value_l2", False),
+             ("global", "key_l2", False), ("global", "value_l2_plus_key_l2", False),
+             ("local", "inverse_key_l2", False),
+             ("global", "value_l2", True), ("local", "value_l2", True),
+             ("inverse_key_l2", None, True)]
+    for ci, (method, formula, use_random) in enumerate(cases):
+        pruner = kp.KVCachePruner("budget", method, bs, budget, 1)
+        if formula is not None:
+            pruner.sub_evict_method = formula
+        me = SimpleNamespace(
+            block_l2norm_mgr=bm.BlockL2NormManager(), kv_cache_pruner=pruner,
+            paged_evict_config=SimpleNamespace(cache_budget=budget, evict_method=method, topk_blocks=topk),
+            cache_config=SimpleNamespace(block_size=bs), num_kv_heads=Hkv, head_size=D,
+            enable_random_evict=use_random)
+        me._create_updated_block_tables = types.MethodType(fns["_create_updated_block_tables"], me)
+        decide = types.MethodType(fns[{"streamingLLM": "_prune_decode_reqs_streamingLLM",
+                                       "streamingLLM-1": "_prune_decode_reqs_streamingLLM",
+                                       "inverse_key_l2": "_prune_decode_reqs_inverseKeyL2"}.get(
+                                           method, "_prune_decode_reqs_topk")], me)
+        random.seed(1234)            # what the impl constructor does (:796)
+        # three sequences (two requests, one of them with two sequences) at staggered lengths;
+        # every table holds the blocks of its physical tokens, free blocks are handed out in order
+        rng = random.Random(100 + ci)
+        free = list(range(nb))
+        rng.shuffle(free)
+        seqs = [("reqA", 0, 61), ("reqB", 3, 50), ("reqB", 4, 77)]      # (request, sequence id, logical length)
+        logical = [L for _, _, L in seqs]
+        physical = [min(L, budget + L % bs) if L > budget else L for L in logical]
+        tables = [[free.pop() for _ in range(-(-p // bs))] for p in physical]
+        init_scores = [[round(rng.uniform(5.0, 60.0), 3) for _ in t[:-1]] for t in tables]
+        mapping = {}
+        for (rid, sid, _), t in zip(seqs, tables):
+            mapping.setdefault(rid, {})[sid] = t
+        me.block_l2norm_mgr.update_reqs(mapping)
+        if method in ("local", "global"):
+            # the prefill driver leaves one score per full prompt block (:1283-1296)
+            for i, sc in enumerate(init_scores):
+                me.block_l2norm_mgr.update_block_l2norms(i, list(sc))
+        trace = {"method": method, "formula": formula, "random": use_random,
+                 "seqs": [[r, s] for r, s, _ in seqs], "init_scores": init_scores, "steps": []}
+        for _ in range(n_steps):
+            # the step's new token: a block is appended when the last one is full
+            for i in range(len(seqs)):
+                if physical[i] % bs == 0:
+                    tables[i].append(free.pop())
+                physical[i] += 1
+                logical[i] += 1
+            me.block_l2norm_mgr.update_reqs(mapping)
+            width = max(len(t) for t in tables)
+            md = SimpleNamespace(seq_lens=list(logical), reqid_mapping_blocktables=mapping,
+                                 decode_metadata=SimpleNamespace(block_tables=pad_tables(tables, width)))
+            step = {"seq_lens": list(logical), "tables": [list(t) for t in tables], "width": width}
+            if method in ("streamingLLM", "streamingLLM-1"):
+                n_zero, zero_map, pruned, upd, rmv = decide(kv_cache, md)
+                step["zero_slots"] = [] if zero_map is None else zero_map.tolist()
+            elif method == "inverse_key_l2":
+                n_zero, zero_map, pruned = decide(kv_cache, md)
+                step["zero_slots"] = [] if zero_map is None else zero_map.tolist()
+                upd, rmv = None, {}
+            else:
+                upd, rmv, pruned = decide(kv_cache, md)
+            step["is_pruned_decode"] = bool(pruned)
+            step["rmv"] = {str(i): [r, int(b)] for i, (r, b) in rmv.items()}
+            step["updated_tables"] = None if upd is None else upd.tolist()
+            if method in ("local", "global") and not use_random:
+                step["scores_after"] = [
+                    [float(x) for x in me.block_l2norm_mgr.reqid_mapping_block_l2norms[r][s]]
+                    for r, s, _ in seqs]
+            trace["steps"].append(step)
+            # engine commit of the layer-0 decision: the victim block leaves the table
+            for i, (_, b) in rmv.items():
+                free.insert(0, tables[i].pop(b))
+                physical[i] -= bs
+        meta["traces"].append(trace)
+
+    np.savez_compressed(os.path.join(HERE, "decode_decisions.npz"), **arrays)
+    with open(os.path.join(HERE, "decode_decisions.json"), "w") as f:
+        json.dump(meta, f)
+    n_ev = sum(len(s["rmv"]) for t in meta["traces"] for s in t["steps"])
+    print(f"decode_decisions: {len(meta['traces'])} traces, {n_ev} evictions")
+    host_logic(ref)
+
+
+if __name__ == "__main__":
+    main()

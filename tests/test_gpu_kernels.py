@@ -405,6 +405,69 @@ def test_evict_topk_trace(ops, oracle, method, topk, drop, layout):
         assert got_table[rows[i], :n].tolist() == scores[i]
 
 
+def test_evict_decisions_reference_golden(ops):
+    """pe_evict_select_compact in its reference-compatible form (victim's score kept, in-loop
+    table slice, the decode call site's flat view of the scored block) against what the
+    reference's own decode-decision methods returned on multi-step traces
+    (tests/golden/make_golden_decode.py): victims, the compacted table tensor, zeroed slots and
+    the score rows after every step; HEAD's random victims go through victim_override."""
+    import json
+    import os
+    from conftest import GOLDEN, from_bits
+    meta = json.load(open(os.path.join(GOLDEN, "decode_decisions.json")))
+    kv = from_bits(np.load(os.path.join(GOLDEN, "decode_decisions.npz"))["kv_cache"], 2)
+    bs, H, D, nb = meta["block_size"], meta["num_kv_heads"], meta["head_size"], meta["num_blocks"]
+    budget, topk = meta["budget"], meta["topk_blocks"]
+    vc_d = kv[1].view(nb, H, D, bs).cuda()
+    ran = 0
+    for tr in meta["traces"]:
+        method, formula, use_random = tr["method"], tr["formula"], tr["random"]
+        if method == "inverse_key_l2" or (formula not in (None, "value_l2")):
+            continue     # host-side draws / key-norm formulas: covered at the backend level
+        B, W = len(tr["seqs"]), 32
+        st_d = torch.zeros((B, W), dtype=torch.float32)
+        sc_d = torch.zeros(B, dtype=torch.int32)
+        for i, sc in enumerate(tr["init_scores"]):
+            st_d[i, :len(sc)] = torch.tensor(sc)
+            sc_d[i] = len(sc)
+        st_d, sc_d = st_d.cuda(), sc_d.cuda()
+        rows_d = torch.arange(B, dtype=torch.int32).cuda()
+        for st in tr["steps"]:
+            tables, M = st["tables"], st["width"]
+            bt = torch.zeros((B, M), dtype=torch.int32)
+            for i, t in enumerate(tables):
+                bt[i, :len(t)] = torch.tensor(t, dtype=torch.int32)
+            nblk = torch.tensor([len(t) for t in tables], dtype=torch.int32)
+            expect = [-1] * B
+            for i, (_, b) in st["rmv"].items():
+                expect[int(i)] = b
+            kw = {}
+            if method in ("local", "global"):
+                if use_random:
+                    kw["victim_override"] = torch.tensor([max(e, 0) for e in expect], dtype=torch.int32).cuda()
+                else:
+                    kw.update(score_table=st_d, score_counts=sc_d, score_rows=rows_d, value_cache=vc_d,
+                              score_layout=ops.SCORE_CACHE_FLAT)
+            rmv, out, zero = ops.evict_select_compact(
+                bt.cuda(), torch.tensor(st["seq_lens"], dtype=torch.int32).cuda(), nblk.cuda(), method,
+                budget, bs, topk, drop_victim_score=False, compat_q1=True, **kw)
+            assert rmv.cpu().tolist() == expect, (method, use_random, st["seq_lens"])
+            if st["updated_tables"] is not None:
+                assert out.cpu().tolist() == st["updated_tables"], (method, st["seq_lens"])
+            if method == "streamingLLM-1":
+                assert [z for z in zero.cpu().tolist() if z >= 0] == st["zero_slots"]
+            if "scores_after" in st:
+                cnt = sc_d.cpu().tolist()
+                tab = st_d.cpu()
+                for i, sc in enumerate(st["scores_after"]):
+                    # the device table holds f32; the prompt scores of the trace are decimal literals
+                    assert cnt[i] == len(sc) and tab[i, :len(sc)].tolist() == torch.tensor(sc).tolist(), \
+                        (method, st["seq_lens"], i)
+        ran += 1
+    assert ran == 6
+    ops.check_device_diagnostics()
+
+
 def test_evict_victim_override(ops, oracle):
     """Host-chosen victims (the reference's random mode) are applied verbatim."""
     bs, budget = 16, 64

@@ -303,3 +303,125 @@ def test_score_formulas_golden(oracle):
                 assert got == pytest.approx(expect, rel=3e-6), (b, f)
             else:
                 assert got == expect, (b, f, got, expect)
+
+
+def _decode_golden():
+    meta = json.load(open(os.path.join(GOLDEN, "decode_decisions.json")))
+    z = np.load(os.path.join(GOLDEN, "decode_decisions.npz"))
+    kv = from_bits(z["kv_cache"], 2)            # [2, num_blocks, bs*H*D] bf16
+    return meta, kv
+
+
+def _padded(tables, width):
+    out = torch.zeros((len(tables), width), dtype=torch.int32)
+    for i, t in enumerate(tables):
+        out[i, :len(t)] = torch.tensor(t, dtype=torch.int32)
+    return out
+
+
+def test_decode_decisions_golden(oracle):
+    """The oracle's decode-time eviction decision against the reference's own methods
+    (_prune_decode_reqs_streamingLLM / _inverseKeyL2 / _topk and _create_updated_block_tables,
+    torch_cuda_sdpa.py:1375-1586, run by tests/golden/make_golden_decode.py on multi-step traces):
+    victims, zeroed slots, the compacted table tensor HEAD builds (in-loop slice included) and the
+    score lists after every step, for every method, the four score formulas, HEAD's random victim
+    and the random zeroed slot of inverse_key_l2."""
+    import random
+    meta, kv = _decode_golden()
+    bs, H, D = meta["block_size"], meta["num_kv_heads"], meta["head_size"]
+    budget, topk = meta["budget"], meta["topk_blocks"]
+    assert len(meta["traces"]) == 10
+    n_evict = 0
+    for tr in meta["traces"]:
+        method, formula, use_random = tr["method"], tr["formula"], tr["random"]
+        scores = [list(s) for s in tr["init_scores"]]
+        stream = oracle.RandomVictimStream(1, seed=1234)
+        rng = random.Random(1234)
+        for st in tr["steps"]:
+            seq_lens, tables = st["seq_lens"], st["tables"]
+            B = len(seq_lens)
+            zero = []
+            if method in ("streamingLLM", "streamingLLM-1"):
+                rmv, zero = oracle.decode_streaming(seq_lens, tables, budget, bs, method)
+            elif method == "inverse_key_l2":
+                rmv = [-1] * B
+                zero = oracle.decode_inverse_key_l2(seq_lens, tables, budget, bs, rng)
+            elif use_random:
+                hit = [i for i in range(B) if oracle.decode_trigger(seq_lens[i], budget, bs)]
+                ranges = [(1, topk) if method == "local" else (1, len(tables[i]) - 2) for i in hit]
+                rmv = [-1] * B
+                for i, v in zip(hit, stream.step(ranges)):
+                    rmv[i] = v
+            else:
+                rmv = []
+                for i in range(B):
+                    if not oracle.decode_trigger(seq_lens[i], budget, bs):
+                        rmv.append(-1)
+                        continue
+                    blk = tables[i][-1]        # scored through the flat re-view of the block (:1521-1524)
+                    k_tm = kv[0, blk].view(bs, H, D)
+                    v_tm = kv[1, blk].view(bs, H, D)
+                    new = oracle.block_score_formula(k_tm, v_tm, formula).float().item()
+                    if formula == "value_l2":
+                        assert new == oracle.block_score(kv[1, blk].view(H, D, bs), bs, H, D, 2)
+                    rmv.append(oracle.decode_topk_victim(scores[i], new, method, topk, False))
+            expect = {int(i): b for i, (_, b) in st["rmv"].items()}
+            assert {i: r for i, r in enumerate(rmv) if r >= 0} == expect, (method, formula, st["seq_lens"])
+            for i, (rid, _) in st["rmv"].items():
+                assert rid == tr["seqs"][int(i)][0]
+            assert st.get("zero_slots", []) == zero
+            assert st["is_pruned_decode"] == (any(r >= 0 for r in rmv) and method != "inverse_key_l2")
+            if st["updated_tables"] is not None:
+                got = oracle.compact_block_tables(_padded(tables, st["width"]), rmv, compat_q1=True)
+                assert got.tolist() == st["updated_tables"], (method, st["seq_lens"])
+            else:
+                assert not any(r >= 0 for r in rmv)
+            if "scores_after" in st:
+                assert scores == st["scores_after"], (method, formula, st["seq_lens"])
+            n_evict += len(expect)
+    assert n_evict == 54
+
+
+def test_host_logic_golden(oracle):
+    """Host-side integer arithmetic against outputs of the reference's own functions
+    (tests/golden/make_golden_decode.py: get_num_required_blocks_after_prune_promt,
+    page_evict_kv_util.py:6-36; _compute_slot_mapping, torch_cuda_sdpa.py:565-598; the kv-length
+    adjustment of _compute_lens, model_runner.py:493-558): the oracle's restatement and the
+    package's host functions must both reproduce them."""
+    from types import SimpleNamespace
+    from vllm_paged_compression_amd import page_evict_kv_util as util
+    from vllm_paged_compression_amd.backend import compute_slot_mapping
+    h = json.load(open(os.path.join(GOLDEN, "host_logic.json")))
+    assert len(h["required_blocks"]) == 1080
+    for bs, budget, method, L, nblk, ntok in h["required_blocks"]:
+        assert oracle.num_required_blocks_after_prune(L, budget, bs) == (nblk, ntok), (bs, budget, L)
+        cfg = SimpleNamespace(cache_prune_type="budget", evict_method=method, cache_budget=budget,
+                              initial_blocks=1)
+        assert util.get_num_required_blocks_after_prune_promt(L, cfg, bs) == (nblk, ntok), (bs, budget, L)
+        if L >= budget:     # what is admitted is what the pruner keeps (kvcache_prunner.py:284-326)
+            assert oracle.pruned_length(L, budget, bs) == ntok
+    assert len(h["slot_mapping"]) == 31
+    for c in h["slot_mapping"]:
+        mine = []
+        compute_slot_mapping(bool(c.get("profile")), c["prompt"], mine, 0, c["query_len"], c["context_len"],
+                             c["bs"], {0: c["table"]})
+        assert mine == c["slots"], c
+        if c.get("profile"):
+            continue
+        if c["prompt"]:
+            assert oracle.prompt_slot_mapping(c["table"], c["query_len"], c["bs"]) == c["slots"]
+        else:
+            assert [oracle.decode_slot(c["table"], c["context_len"], c["bs"])] == c["slots"]
+    assert len(h["kv_len_adjust"]) == 135
+    adjusted = 0
+    for method, bs, budget, seq_len, kv_before, kv_after, q_len, ctx, pos in h["kv_len_adjust"]:
+        # (PagedEvictConfig raises budgets below 128 as the reference's does: a plain record here)
+        cfg = SimpleNamespace(cache_prune_type="budget", evict_method=method, cache_budget=budget,
+                              topk_blocks=3)
+        assert util.adjust_seq_kv_len(cfg, seq_len, kv_before, bs) == kv_after, (method, bs, budget, seq_len)
+        assert util.evicted_tokens(cfg, seq_len, kv_before, bs) == kv_before - kv_after
+        trig = method != "inverse_key_l2" and oracle.decode_trigger(seq_len, budget, bs)
+        assert kv_before - kv_after == (bs if trig else 0)
+        assert (q_len, ctx, pos) == (1, seq_len - 1, seq_len - 1)
+        adjusted += kv_before != kv_after
+    assert adjusted == 36     # 4 block-evicting methods x 3 geometries x 3 block-boundary lengths
