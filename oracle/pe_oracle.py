@@ -569,12 +569,27 @@ def table_remove_range(tables: torch.Tensor, start: Sequence[int], n_remove: int
 
 # --------------------------------------------------------------------------- block-table counters
 
+class NaiveAllocator:
+    """Hand-out order of NaiveBlockAllocator (vllm/core/block/naive_block.py:127-145): ids come
+    off the front of a deque that starts as 0..n-1, a freed id returns to the front."""
+
+    def __init__(self, num_blocks: int):
+        self.free_ids = list(range(num_blocks))
+
+    def take(self) -> int:
+        return self.free_ids.pop(0)
+
+    def give(self, block_id: int) -> None:
+        self.free_ids.insert(0, block_id)
+
+
 class BlockTableCounters:
     """The two counters the fork adds to BlockTable (vllm/core/block/block_table.py:
     58-66,119-126,188-196,456-466): ``num_full_slots`` (logical tokens) and
-    ``num_cached_slots`` (tokens physically cached), plus the block-id list."""
+    ``num_cached_slots`` (tokens physically cached), plus the block-id list.  With
+    ``allocator`` (a NaiveAllocator shared by several tables) the ids are the reference's."""
 
-    def __init__(self, block_size: int, budget: Optional[int]):
+    def __init__(self, block_size: int, budget: Optional[int], allocator: Optional[NaiveAllocator] = None):
         self.bs = block_size
         self.budget = budget
         self.blocks: List[int] = []
@@ -582,13 +597,23 @@ class BlockTableCounters:
         self.num_cached_slots = 0
         self._next = 0
         self.freed: List[int] = []
+        self.allocator = allocator
 
     def _new_block(self) -> int:
+        if self.allocator is not None:
+            return self.allocator.take()
         if self.freed:
             return self.freed.pop(0)
         b = self._next
         self._next += 1
         return b
+
+    def free_all(self) -> None:
+        """BlockTable.free, block_table.py:260-271: blocks are freed front to back."""
+        for b in self.blocks:
+            if self.allocator is not None:
+                self.allocator.give(b)
+        self.blocks = []
 
     def allocate(self, n_tokens: int) -> None:
         if self.budget is None:
@@ -610,7 +635,10 @@ class BlockTableCounters:
         self.num_cached_slots += 1
 
     def free_pruned_block(self, idx: int) -> None:
-        self.freed.append(self.blocks[idx])
+        if self.allocator is not None:
+            self.allocator.give(self.blocks[idx])
+        else:
+            self.freed.append(self.blocks[idx])
         self.num_cached_slots -= self.bs
         del self.blocks[idx]
 

@@ -151,6 +151,129 @@ def host_logic(ref):
           f"mappings, {len(out['kv_len_adjust'])} kv-length rows")
 
 
+def block_table_traces(ref):
+    """Block bookkeeping from the reference's own classes: ``BlockTable``
+    (vllm/core/block/block_table.py) on a ``NaiveBlockAllocator`` (vllm/core/block/naive_block.py),
+    loaded from their files with the three names they take from ``vllm.utils`` (Device, cdiv,
+    chunk_list) and ``PagedEvictConfig`` provided by stub modules, and a four-method adapter that
+    drops the ``device`` argument the device-aware allocator front end would dispatch on.  Every
+    trace shares one allocator between several sequences: pruned prompt allocation, one token per
+    step, the victim block freed after the step where the trigger fires (llm_engine.py:1179-1193),
+    a sequence finishing and a new one admitted.  Recorded after every step: block ids, logical
+    length, cached length, free blocks."""
+    import enum
+    import sys
+
+    class Device(enum.Enum):
+        GPU = enum.auto()
+        CPU = enum.auto()
+
+    def chunk_list(lst, n):
+        for i in range(0, len(lst), n):
+            yield lst[i:i + n]
+
+    utils = types.ModuleType("vllm.utils")
+    utils.Device, utils.cdiv, utils.chunk_list = Device, (lambda a, b: -(a // -b)), chunk_list
+    cfgm = types.ModuleType("vllm.config")
+    cfgm.PagedEvictConfig = object
+    names = ("vllm", "vllm.core", "vllm.core.block", "vllm.utils", "vllm.config",
+             "vllm.core.block.interfaces", "vllm.core.block.common", "vllm.core.block.naive_block",
+             "vllm.core.page_evict_kv_util", "vllm.core.block.block_table")
+    saved = {k: sys.modules.get(k) for k in names}
+
+    def load_as(name, path):
+        spec = importlib.util.spec_from_file_location(name, path)
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[name] = m
+        spec.loader.exec_module(m)
+        return m
+
+    try:
+        for n in ("vllm", "vllm.core", "vllm.core.block"):
+            sys.modules[n] = types.ModuleType(n)
+            sys.modules[n].__path__ = []
+        sys.modules["vllm.utils"], sys.modules["vllm.config"] = utils, cfgm
+        load_as("vllm.core.block.interfaces", f"{ref}/vllm/core/block/interfaces.py")
+        load_as("vllm.core.block.common", f"{ref}/vllm/core/block/common.py")
+        nbm = load_as("vllm.core.block.naive_block", f"{ref}/vllm/core/block/naive_block.py")
+        load_as("vllm.core.page_evict_kv_util", f"{ref}/vllm/core/page_evict_kv_util.py")
+        btm = load_as("vllm.core.block.block_table", f"{ref}/vllm/core/block/block_table.py")
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+    class OnGpu:
+        def __init__(self, a):
+            self.a = a
+
+        def allocate_mutable_block(self, prev_block, device, extra_hash=None):
+            return self.a.allocate_mutable_block(prev_block, extra_hash=extra_hash)
+
+        def allocate_immutable_block(self, prev_block, token_ids, device, extra_hash=None):
+            return self.a.allocate_immutable_block(prev_block, token_ids, extra_hash=extra_hash)
+
+        def allocate_immutable_blocks(self, prev_block, block_token_ids, device, extra_hash=None):
+            return self.a.allocate_immutable_blocks(prev_block, block_token_ids, extra_hash=extra_hash)
+
+        def free(self, block):
+            self.a.free(block)
+
+    traces = []
+    for ti, (bs, budget, nblocks, prompts, late, policy) in enumerate([
+            (16, 64, 48, [100, 61, 130], 75, "second"), (16, 64, 48, [100, 61, 130], 75, "middle"),
+            (8, 48, 64, [33, 200, 48, 49], 90, "middle"), (16, 128, 64, [1024, 130, 128], 300, "second"),
+            (16, 64, 40, [64, 65, 80], 17, None)]):
+        cfg = None if policy is None else SimpleNamespace(
+            cache_budget=budget, initial_blocks=1, evict_method="global", cache_prune_type="budget")
+        alloc = nbm.NaiveBlockAllocator(create_block=nbm.NaiveBlock, num_blocks=nblocks, block_size=bs)
+        rng = random.Random(50 + ti)
+        live = {}
+
+        def admit(name, n):
+            t = btm.BlockTable(bs, OnGpu(alloc), paged_evict_config=cfg)
+            t.allocate(list(range(n)))
+            live[name] = t
+
+        def snap():
+            return {k: [list(t.physical_block_ids), t._num_full_slots, t.get_seq_kv_len()]
+                    for k, t in live.items()}
+
+        for i, n in enumerate(prompts):
+            admit(f"s{i}", n)
+        tr = {"bs": bs, "budget": budget, "num_blocks": nblocks, "prompts": prompts, "late_prompt": late,
+              "evict": policy is not None, "after_prefill": snap(), "free_after_prefill": alloc.get_num_free_blocks(),
+              "steps": []}
+        for step in range(60):
+            ev = {}
+            if step == 20:
+                live.pop("s1").free()
+                ev["finished"] = "s1"
+            if step == 23:
+                admit("late", late)
+                ev["admitted"] = "late"
+            for t in live.values():
+                t.append_token_ids([7])
+            rmv = {}
+            if cfg is not None:
+                for k, t in live.items():
+                    L = t._num_full_slots
+                    if L > budget and L % bs == 0:
+                        n = len(t.physical_block_ids)
+                        rmv[k] = 1 if policy == "second" else rng.randint(1, n - 2)
+                for k, idx in rmv.items():
+                    live[k].free_prunned_blocks(idx)
+            ev.update(rmv=rmv, state=snap(), free=alloc.get_num_free_blocks())
+            tr["steps"].append(ev)
+        traces.append(tr)
+    with open(os.path.join(HERE, "block_table_traces.json"), "w") as f:
+        json.dump(traces, f)
+    print(f"block_table_traces: {len(traces)} traces, "
+          f"{sum(len(s['rmv']) for t in traces for s in t['steps'])} evictions")
+
+
 def bits(t):
     return t.contiguous().view(torch.int16).numpy().view(np.uint16).copy()
 
@@ -260,6 +383,7 @@ def main():
     n_ev = sum(len(s["rmv"]) for t in meta["traces"] for s in t["steps"])
     print(f"decode_decisions: {len(meta['traces'])} traces, {n_ev} evictions")
     host_logic(ref)
+    block_table_traces(ref)
 
 
 if __name__ == "__main__":

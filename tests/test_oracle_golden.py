@@ -425,3 +425,88 @@ def test_host_logic_golden(oracle):
         assert (q_len, ctx, pos) == (1, seq_len - 1, seq_len - 1)
         adjusted += kv_before != kv_after
     assert adjusted == 36     # 4 block-evicting methods x 3 geometries x 3 block-boundary lengths
+
+
+def test_block_table_traces_golden(oracle):
+    """Block bookkeeping against traces of the reference's own BlockTable on its
+    NaiveBlockAllocator (tests/golden/make_golden_decode.py): block ids (the allocator's hand-out
+    order included), logical and cached lengths and the free-block count after every step, for the
+    oracle's counters, the per-request table/scheduler and the vectorised scheduler."""
+    from types import SimpleNamespace
+    from vllm_paged_compression_amd.batch_scheduler import BatchEvictionScheduler
+    from vllm_paged_compression_amd.block_table import (BlockAllocator, EvictBlockSpaceManager, EvictBlockTable,
+                                                        EvictionScheduler)
+    traces = json.load(open(os.path.join(GOLDEN, "block_table_traces.json")))
+    assert len(traces) == 5
+    evictions = 0
+    for tr in traces:
+        bs, budget, nb = tr["bs"], tr["budget"], tr["num_blocks"]
+        cfg = None
+        if tr["evict"]:
+            cfg = SimpleNamespace(cache_prune_type="budget", evict_method="global", cache_budget=budget,
+                                  initial_blocks=1, topk_blocks=3)
+        # --- oracle counters and the package's table, each on one shared allocator
+        o_alloc, p_alloc = oracle.NaiveAllocator(nb), BlockAllocator(nb)
+        o_live, p_live = {}, {}
+        per_req = EvictionScheduler(EvictBlockSpaceManager(bs, nb, cfg, watermark=0.0))
+        vec = BatchEvictionScheduler(bs, nb, cfg, max_seqs=8, max_blocks_per_seq=128)
+        order = []
+
+        def admit(name, n):
+            o = oracle.BlockTableCounters(bs, budget if tr["evict"] else None, o_alloc)
+            o.allocate(n)
+            o_live[name] = o
+            p = EvictBlockTable(bs, p_alloc, cfg)
+            p.allocate(n)
+            p_live[name] = p
+            per_req.add_request(name, len(order) + 10, n)
+            vec.add_request(name, len(order) + 10, n)
+            order.append(name)
+
+        def check(state, free):
+            assert list(state) == [n for n in order if n in o_live]
+            for name, (ids, full, cached) in state.items():
+                o, p = o_live[name], p_live[name]
+                assert (o.blocks, o.num_full_slots, o.num_cached_slots) == (ids, full, cached), name
+                assert (p.physical_block_ids, p.num_full_slots, p.get_seq_kv_len()) == (ids, full, cached), name
+                assert vec.get_block_table(name) == ids and vec.get_seq_kv_len(name) == cached, name
+            assert len(o_alloc.free_ids) == free and p_alloc.get_num_free_blocks() == free
+            assert per_req.block_manager.get_num_free_gpu_blocks() == free
+            assert vec.get_num_free_gpu_blocks() == free
+
+        for i, n in enumerate(tr["prompts"]):
+            admit(f"s{i}", n)
+        check(tr["after_prefill"], tr["free_after_prefill"])
+        for st in tr["steps"]:
+            if "finished" in st:
+                name = st["finished"]
+                o_live.pop(name).free_all()
+                p_live.pop(name).free()
+                per_req.finish_request(name)
+                vec.finish_request(name)
+            if "admitted" in st:
+                admit(st["admitted"], tr["late_prompt"])
+            live = [n for n in order if n in o_live]
+            for n in live:
+                o_live[n].append_token()
+                p_live[n].append_token_ids(1)
+            tables, kv_lens = per_req.schedule_decode(live)
+            vec.schedule_decode(live)
+            commit = {}
+            for n, idx in st["rmv"].items():
+                # the trigger the engine acts on (model_runner.py:541)
+                assert oracle.decode_trigger(o_live[n].num_full_slots, budget, bs)
+                o_live[n].free_pruned_block(idx)
+                p_live[n].free_prunned_blocks(idx)
+                commit[live.index(n)] = (n, idx)
+            for n in live:
+                if n not in st["rmv"] and tr["evict"]:
+                    assert not oracle.decode_trigger(o_live[n].num_full_slots, budget, bs)
+            per_req.commit(commit)
+            vec.commit(commit)
+            evictions += len(commit)
+            check(st["state"], st["free"])
+            for n in live:      # the per-request scheduler hands out the same tables
+                sid = [k for k in tables][live.index(n)]
+                assert per_req.block_manager.get_block_table(sid) == st["state"][n][0]
+    assert evictions == 57

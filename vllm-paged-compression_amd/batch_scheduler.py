@@ -147,9 +147,13 @@ class BatchEvictionScheduler:
         return out
 
     def _give(self, ids: np.ndarray) -> None:
+        """Freed ids go back to the FRONT of the list one after the other, as the reference's
+        allocator does (vllm/core/block/naive_block.py:139-145): the id freed last is handed out
+        first."""
         n = len(ids)
         cap = len(self._free)
-        self._free[(self._head + self._n_free + np.arange(n)) % cap] = ids
+        self._head = (self._head - n) % cap
+        self._free[(self._head + np.arange(n)) % cap] = np.asarray(ids)[::-1]
         self._n_free += n
 
     # ---- requests ----------------------------------------------------------------------------

@@ -25,7 +25,10 @@ from .page_evict_kv_util import cdiv, get_num_required_blocks_after_prune_promt
 
 
 class BlockAllocator:
-    """Free-list allocator of physical block ids [0, num_blocks)."""
+    """Free-list allocator of physical block ids [0, num_blocks) with the hand-out order of the
+    reference's NaiveBlockAllocator (vllm/core/block/naive_block.py:127-145): ids are taken from
+    the front of the list and a freed id goes back to the FRONT, so the block freed last is the
+    next one handed out."""
 
     def __init__(self, num_blocks: int):
         self.num_blocks = num_blocks
@@ -40,7 +43,7 @@ class BlockAllocator:
         return self._free.popleft()
 
     def free(self, block_id: int) -> None:
-        self._free.append(block_id)
+        self._free.appendleft(block_id)
 
 
 class EvictBlockTable:
