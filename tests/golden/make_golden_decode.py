@@ -145,10 +145,47 @@ def host_logic(ref):
                 rows.append([method, bs, budget, seq_len, kv_before, inter.seq_kv_lens[5], inter.query_lens[0],
                              inter.context_lens[0], inter.input_positions[0][0]])
     out["kv_len_adjust"] = rows
+
+    # admission: SelfAttnBlockSpaceManager.can_allocate (vllm/core/block_manager.py:113-156) with the
+    # names it takes from its module given as the reference's own function / plain stand-ins
+    import enum
+
+    class AllocStatus(enum.Enum):
+        OK = enum.auto()
+        LATER = enum.auto()
+        NEVER = enum.auto()
+
+    class PlainTable:
+        @staticmethod
+        def get_num_required_blocks(token_ids, block_size, num_lookahead_slots=0):
+            return -((len(token_ids) + num_lookahead_slots) // -block_size)     # block_table.py:70-92
+
+    can = reference_function(
+        f"{ref}/vllm/core/block_manager.py", "can_allocate", "SelfAttnBlockSpaceManager",
+        extra={"SequenceGroup": object, "AllocStatus": AllocStatus, "BlockTable": PlainTable,
+               "SequenceStatus": SimpleNamespace(WAITING=0), "Device": SimpleNamespace(GPU=0),
+               "check_no_caching_or_swa_for_blockmgr_encdec": lambda *a: None,
+               "get_num_required_blocks_after_prune_promt": req})
+    rows = []
+    for bs, budget in ((16, 64), (16, 768), (8, 48)):
+        for evict in (False, True):
+            cfg = SimpleNamespace(cache_budget=budget, initial_blocks=1, evict_method="global",
+                                  cache_prune_type="budget") if evict else None
+            for total, watermark in ((64, 0), (64, 1), (100, 1), (1000, 10)):
+                for free in (0, 3, 5, 6, 49, 50, 63, total):
+                    for L in (1, budget - 1, budget, budget + 1, 100, 1024, 1030, 16 * total, 16 * total + 1):
+                        mgr = SimpleNamespace(
+                            paged_evict_config=cfg, block_size=bs, max_block_sliding_window=None,
+                            num_total_gpu_blocks=total, watermark_blocks=watermark,
+                            block_allocator=SimpleNamespace(get_num_free_blocks=lambda device, f=free: f))
+                        seq = SimpleNamespace(get_token_ids=lambda n=L: [0] * n)
+                        grp = SimpleNamespace(get_seqs=lambda status, s=seq: [s], is_encoder_decoder=lambda: False)
+                        rows.append([bs, budget, int(evict), total, watermark, free, L, can(mgr, grp).name])
+    out["can_allocate"] = rows
     with open(os.path.join(HERE, "host_logic.json"), "w") as f:
         json.dump(out, f)
-    print(f"host_logic: {len(out['required_blocks'])} admission rows, {len(out['slot_mapping'])} slot "
-          f"mappings, {len(out['kv_len_adjust'])} kv-length rows")
+    print(f"host_logic: {len(out['required_blocks'])} pruned-size rows, {len(out['slot_mapping'])} slot "
+          f"mappings, {len(out['kv_len_adjust'])} kv-length rows, {len(out['can_allocate'])} admission rows")
 
 
 def block_table_traces(ref):

@@ -510,3 +510,23 @@ def test_block_table_traces_golden(oracle):
                 sid = [k for k in tables][live.index(n)]
                 assert per_req.block_manager.get_block_table(sid) == st["state"][n][0]
     assert evictions == 57
+
+
+def test_admission_golden():
+    """EvictBlockSpaceManager.can_allocate against SelfAttnBlockSpaceManager.can_allocate
+    (vllm/core/block_manager.py:113-156) run by tests/golden/make_golden_decode.py."""
+    from types import SimpleNamespace
+    from vllm_paged_compression_amd.block_table import EvictBlockSpaceManager
+    rows = json.load(open(os.path.join(GOLDEN, "host_logic.json")))["can_allocate"]
+    assert len(rows) == 1728
+    seen = set()
+    for bs, budget, evict, total, watermark, free, L, status in rows:
+        cfg = SimpleNamespace(cache_prune_type="budget", evict_method="global", cache_budget=budget,
+                              initial_blocks=1, topk_blocks=3) if evict else None
+        m = EvictBlockSpaceManager(bs, total, cfg, watermark=0.0)
+        m.watermark_blocks = watermark
+        for _ in range(total - free):
+            m.allocator.allocate()
+        assert m.can_allocate(L) == status, (bs, budget, evict, total, watermark, free, L)
+        seen.add(status)
+    assert seen == {"OK", "LATER", "NEVER"}
