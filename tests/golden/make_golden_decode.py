@@ -311,8 +311,70 @@ def block_table_traces(ref):
           f"{sum(len(s['rmv']) for t in traces for s in t['steps'])} evictions")
 
 
+def prefill_driver(ref, kp, bm):
+    """The batch driver of the prompt prune, TorchCUDASDPABackendImpl._prune_prompts_keys_and_values_new
+    (torch_cuda_sdpa.py:1222-1296), compiled from the reference file and run on CPU tensors.  The
+    method spreads the requests over CUDA side streams (a scheduling detail without effect on the
+    result); the ``torch`` it sees here forwards everything to the real module except
+    ``torch.cuda.stream`` / ``current_stream``, which do nothing.  Written per case: K/V of the
+    batch, the concatenated pruned K/V the method returned and the per-request block-score lists
+    it left in the BlockL2NormManager."""
+    import contextlib
+
+    class TorchOnCpu:
+        cuda = SimpleNamespace(stream=lambda s: contextlib.nullcontext(),
+                               current_stream=lambda: SimpleNamespace(wait_stream=lambda s: None))
+
+        def __getattr__(self, name):
+            return getattr(torch, name)
+
+    drv = reference_function(f"{ref}/vllm/attention/backends/torch_cuda_sdpa.py",
+                             "_prune_prompts_keys_and_values_new", "TorchCUDASDPABackendImpl",
+                             extra={"torch": TorchOnCpu(), "TorchCUDASDPAMetadata": object})
+    bs, H, D, budget = 16, 2, 32, 64
+    arrays, cases = {}, []
+    for ci, (method, formula, lens) in enumerate([
+            ("streamingLLM", None, [100, 40, 130]), ("global", "value_l2", [100, 40, 130]),
+            ("global", "key_l2", [97, 64, 65]), ("local", "value_l2_plus_key_l2", [200, 81]),
+            ("global", "inverse_key_l2", [128, 129]), ("inverse_key_l2", None, [100, 70]),
+            ("global", "value_l2", [30, 64])]):
+        g = torch.Generator().manual_seed(600 + ci)
+        T = sum(lens)
+        # token-level prunes rank (token, head) norms: f32 inputs keep them free of ties (the order
+        # torch.topk gives equal scores is pinned by nothing); the slice-only method runs in bf16
+        dt = torch.bfloat16 if method == "streamingLLM" else torch.float32
+        key = (torch.rand(T, H, D, generator=g) * 2 - 1).to(dt)
+        value = (torch.rand(T, H, D, generator=g) * 2 - 1).to(dt)
+        pruner = kp.KVCachePruner("budget", method, bs, budget, 1)
+        if formula is not None:
+            pruner.sub_evict_method = formula
+        mgr = bm.BlockL2NormManager()
+        mapping = {f"r{i}": {i: [0] * 8} for i in range(len(lens))}
+        mgr.update_reqs(mapping)
+        me = SimpleNamespace(streams=[None, None], kv_cache_pruner=pruner, num_kv_heads=H, head_size=D,
+                             paged_evict_config=SimpleNamespace(evict_method=method),
+                             cache_config=SimpleNamespace(block_size=bs), enable_random_evict=False,
+                             block_l2norm_mgr=mgr)
+        pk, pv = drv(me, key, value, SimpleNamespace(seq_lens=list(lens)), False)
+        scores = None
+        if method in ("local", "global") and pk is not key:
+            scores = [[float(x) for x in mgr.reqid_mapping_block_l2norms[f"r{i}"][i]] for i in range(len(lens))]
+        arrays[f"c{ci}_k"], arrays[f"c{ci}_v"] = raw(key), raw(value)
+        arrays[f"c{ci}_pk"], arrays[f"c{ci}_pv"] = raw(pk), raw(pv)
+        cases.append({"method": method, "formula": formula, "lens": lens, "returned_input": pk is key,
+                      "dtype": 2 if dt == torch.bfloat16 else 0, "scores": scores})
+    np.savez_compressed(os.path.join(HERE, "prefill_driver.npz"), **arrays)
+    with open(os.path.join(HERE, "prefill_driver.json"), "w") as f:
+        json.dump({"block_size": bs, "num_kv_heads": H, "head_size": D, "budget": budget, "cases": cases}, f)
+    print(f"prefill_driver: {len(cases)} cases")
+
+
 def bits(t):
     return t.contiguous().view(torch.int16).numpy().view(np.uint16).copy()
+
+
+def raw(t):
+    return bits(t) if t.dtype == torch.bfloat16 else t.contiguous().numpy().copy()
 
 
 def pad_tables(tables, width):
@@ -421,6 +483,7 @@ def main():
     print(f"decode_decisions: {len(meta['traces'])} traces, {n_ev} evictions")
     host_logic(ref)
     block_table_traces(ref)
+    prefill_driver(ref, kp, bm)
 
 
 if __name__ == "__main__":

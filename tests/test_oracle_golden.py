@@ -530,3 +530,42 @@ def test_admission_golden():
         assert m.can_allocate(L) == status, (bs, budget, evict, total, watermark, free, L)
         seen.add(status)
     assert seen == {"OK", "LATER", "NEVER"}
+
+
+def test_prefill_driver_golden(oracle):
+    """The batch driver of the prompt prune against the reference's own
+    _prune_prompts_keys_and_values_new (torch_cuda_sdpa.py:1222-1296, run by
+    tests/golden/make_golden_decode.py): the concatenated pruned K/V of a batch and the block
+    scores it leaves per request (one per full block of the pruned prompt, every formula).  HEAD
+    returns the input and scores nothing when no request of the batch exceeds the budget."""
+    meta = json.load(open(os.path.join(GOLDEN, "prefill_driver.json")))
+    z = np.load(os.path.join(GOLDEN, "prefill_driver.npz"))
+    bs, H, D, budget = meta["block_size"], meta["num_kv_heads"], meta["head_size"], meta["budget"]
+    assert len(meta["cases"]) == 7
+    for ci, c in enumerate(meta["cases"]):
+        dt = c["dtype"]
+        k, v = from_bits(z[f"c{ci}_k"], dt), from_bits(z[f"c{ci}_v"], dt)
+        pk, pv = from_bits(z[f"c{ci}_pk"], dt), from_bits(z[f"c{ci}_pv"], dt)
+        outs_k, outs_v, scores, off = [], [], [], 0
+        for n in c["lens"]:
+            a, b = oracle.prompt_prune(k[off:off + n], v[off:off + n], c["method"], budget, bs,
+                                       formula=c["formula"] or "value_l2", compat_q2=True)
+            assert a.shape[0] == oracle.pruned_length(n, budget, bs)
+            outs_k.append(a)
+            outs_v.append(b)
+            if c["formula"] is not None:
+                scores.append([oracle.block_score_formula(a[i * bs:(i + 1) * bs].contiguous(),
+                                                          b[i * bs:(i + 1) * bs].contiguous(),
+                                                          c["formula"]).float().item()
+                               for i in range(a.shape[0] // bs)])
+            off += n
+        assert torch.equal(torch.cat(outs_k), pk) and torch.equal(torch.cat(outs_v), pv), c
+        if c["returned_input"]:
+            assert all(n <= budget for n in c["lens"]) and torch.equal(pk, k) and c["scores"] is None
+        elif c["formula"] is not None:
+            # f32 inputs: torch's vectorised summation order is not reproduced (a few ulp)
+            assert [len(x) for x in scores] == [len(x) for x in c["scores"]]
+            for mine, ref in zip(scores, c["scores"]):
+                assert mine == pytest.approx(ref, rel=3e-6), c
+        else:
+            assert c["scores"] is None
