@@ -331,7 +331,7 @@ def prefill_driver(ref, kp, bm):
     drv = reference_function(f"{ref}/vllm/attention/backends/torch_cuda_sdpa.py",
                              "_prune_prompts_keys_and_values_new", "TorchCUDASDPABackendImpl",
                              extra={"torch": TorchOnCpu(), "TorchCUDASDPAMetadata": object})
-    bs, H, D, budget = 16, 2, 32, 64
+    bs, H, D, budget = 16, 2, 16, 64
     arrays, cases = {}, []
     for ci, (method, formula, lens) in enumerate([
             ("streamingLLM", None, [100, 40, 130]), ("global", "value_l2", [100, 40, 130]),
