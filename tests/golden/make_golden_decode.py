@@ -369,6 +369,53 @@ def prefill_driver(ref, kp, bm):
     print(f"prefill_driver: {len(cases)} cases")
 
 
+def sdpa_inputs(seed, lens_q, lens_kv, Hq, Hkv, D):
+    """bf16 inputs of an sdpa_forward case, regenerated from the seed by the tests."""
+    g = torch.Generator().manual_seed(seed)
+    sc = D ** -0.5
+    q = ((torch.rand(sum(lens_q), Hq, D, generator=g) * 2 - 1) * 3 * sc).to(torch.bfloat16)
+    k = ((torch.rand(sum(lens_kv), Hkv, D, generator=g) * 2 - 1) * 3 * sc).to(torch.bfloat16)
+    v = (torch.rand(sum(lens_kv), Hkv, D, generator=g) * 2 - 1).to(torch.bfloat16)
+    return q, k, v
+
+
+def sdpa_forward(ref):
+    """Prefill attention as the reference composes it: TorchCUDASDPABackendImpl._run_sdpa_forward
+    (torch_cuda_sdpa.py:1069-1127) compiled from the reference file and run on CPU in f32 over
+    bf16-representable inputs - grouped heads through repeat_interleave, one
+    scaled_dot_product_attention(is_causal=True) per request, kv offsets advancing by the PRUNED
+    lengths when the prompt was pruned before attention (top-left aligned mask for L_q != L_kv),
+    or by the query lengths with disable_evict_prefill.  Stored: the f32 outputs (inputs come
+    from sdpa_inputs(seed))."""
+    from torch.nn.functional import scaled_dot_product_attention
+    fn = reference_function(f"{ref}/vllm/attention/backends/torch_cuda_sdpa.py", "_run_sdpa_forward",
+                            "TorchCUDASDPABackendImpl",
+                            extra={"torch": torch, "TorchCUDASDPAMetadata": object,
+                                   "AttentionType": SimpleNamespace(DECODER="decoder"),
+                                   "scaled_dot_product_attention": scaled_dot_product_attention})
+    arrays, cases = {}, []
+    for ci, (Hq, Hkv, D, lens_q, lens_kv, disable) in enumerate([
+            (4, 2, 64, [90, 24, 50], [58, 24, 50], False), (4, 2, 64, [90, 24, 50], [90, 24, 50], True),
+            (8, 1, 128, [20, 70], [20, 38], False), (4, 4, 64, [1, 17, 64], [1, 17, 64], True)]):
+        q, k, v = sdpa_inputs(900 + ci, lens_q, lens_kv, Hq, Hkv, D)
+        me = SimpleNamespace(num_heads=Hq, num_kv_heads=Hkv, num_queries_per_kv=Hq // Hkv,
+                             alibi_slopes=None, sliding_window=None, enabled_paged_eviction=True,
+                             paged_evict_config=SimpleNamespace(disable_evict_prefill=disable),
+                             scale=D ** -0.5)
+        md = SimpleNamespace(get_attn_bias=lambda t: None, set_attn_bias=lambda m, t: None,
+                             get_seq_lens=lambda t, a=lens_q, b=lens_kv: (list(a), list(b)),
+                             seq_lens=list(lens_q))
+        out = torch.zeros(sum(lens_q), Hq, D, dtype=torch.float32)
+        fn(me, out, q.float(), k.float(), v.float(), md)
+        arrays[f"c{ci}_out"] = out.numpy().copy()
+        cases.append({"seed": 900 + ci, "Hq": Hq, "Hkv": Hkv, "D": D, "lens_q": lens_q, "lens_kv": lens_kv,
+                      "disable_evict_prefill": disable})
+    np.savez_compressed(os.path.join(HERE, "sdpa_forward.npz"), **arrays)
+    with open(os.path.join(HERE, "sdpa_forward.json"), "w") as f:
+        json.dump(cases, f)
+    print(f"sdpa_forward: {len(cases)} cases")
+
+
 def bits(t):
     return t.contiguous().view(torch.int16).numpy().view(np.uint16).copy()
 
@@ -484,6 +531,7 @@ def main():
     host_logic(ref)
     block_table_traces(ref)
     prefill_driver(ref, kp, bm)
+    sdpa_forward(ref)
 
 
 if __name__ == "__main__":

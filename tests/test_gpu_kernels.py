@@ -520,6 +520,22 @@ def test_prefill_causal(ops, oracle, Hq, Hkv, D, dtype, q_lens, kv_lens):
     torch.testing.assert_close(out.cpu().float(), ref, atol=tol[0], rtol=tol[1])
 
 
+def test_prefill_reference_sdpa_forward_golden(ops):
+    """pe_prefill_causal against outputs of the reference's own _run_sdpa_forward
+    (torch_cuda_sdpa.py:1069-1127; run in f32 on CPU by tests/golden/make_golden_decode.py over the
+    same bf16 inputs): grouped heads, per-request kv offsets by the pruned lengths, top-left
+    aligned mask.  Tolerance of a bf16 kernel against an f32 result: atol 2e-2, rtol 1.6e-2 (the
+    rounding of the CUDA SDPA kernel the reference would run is pinned by nothing)."""
+    from test_oracle_golden import sdpa_cases
+    n = 0
+    for c, q, k, v, ref in sdpa_cases():
+        out = ops.prefill_causal(q.cuda(), k.cuda(), v.cuda(), _cu(c["lens_q"]).cuda(),
+                                 _cu(c["lens_kv"]).cuda(), max(c["lens_q"]), c["D"] ** -0.5)
+        torch.testing.assert_close(out.cpu().float(), ref, atol=2e-2, rtol=1.6e-2)
+        n += 1
+    assert n == 4
+
+
 def test_prefill_matches_torch_sdpa_top_left(ops):
     """The mask alignment is the one torch SDPA(is_causal=True) uses for L_q != L_kv."""
     g = torch.Generator().manual_seed(4)

@@ -569,3 +569,31 @@ def test_prefill_driver_golden(oracle):
                 assert mine == pytest.approx(ref, rel=3e-6), c
         else:
             assert c["scores"] is None
+
+
+def sdpa_cases():
+    """Cases of tests/golden/sdpa_forward.*: (case dict, q, k, v bf16 regenerated from the seed,
+    f32 output of the reference's _run_sdpa_forward)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_decode",
+                                                  os.path.join(GOLDEN, "make_golden_decode.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    cases = json.load(open(os.path.join(GOLDEN, "sdpa_forward.json")))
+    z = np.load(os.path.join(GOLDEN, "sdpa_forward.npz"))
+    for ci, c in enumerate(cases):
+        q, k, v = gen.sdpa_inputs(c["seed"], c["lens_q"], c["lens_kv"], c["Hq"], c["Hkv"], c["D"])
+        yield c, q, k, v, torch.from_numpy(z[f"c{ci}_out"])
+
+
+def test_sdpa_forward_golden(oracle):
+    """The oracle's prefill attention against the reference's own _run_sdpa_forward
+    (torch_cuda_sdpa.py:1069-1127) run in f32: grouped-head mapping, per-request offsets by the
+    pruned kv lengths, top-left aligned causal mask when L_q != L_kv.  f32 against f32: 2e-6."""
+    n = 0
+    for c, q, k, v, ref in sdpa_cases():
+        got = oracle.prefill_attention(q.float(), k.float(), v.float(), c["lens_q"], c["lens_kv"],
+                                       c["D"] ** -0.5)
+        torch.testing.assert_close(got, ref, atol=2e-6, rtol=2e-6)
+        n += 1
+    assert n == 4
