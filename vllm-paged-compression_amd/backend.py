@@ -877,7 +877,8 @@ class PagedEvictImpl(_ImplBase):
             self._score_table.retain_only(keys)
         st = getattr(batch, "device_state", None) if batch is not None else None
         if st is not None and not (self.compat.per_layer_decision or self.compat.block_table_slice_in_loop
-                                   or self.compat.streaming_decode_original_table):
+                                   or self.compat.streaming_decode_original_table
+                                   or self.compat.compacted_table_strided_view):
             dec = self._decode_decision_device(st, dm, L, table_of, keys, req_ids, value_cache,
                                                key_cache)
             step["decode"] = dec
@@ -973,6 +974,11 @@ class PagedEvictImpl(_ImplBase):
                 if self._tp_size() > 1 and new_scores is None:
                     parallel.broadcast_victims(rmv, self.tp_group, 0)
                 dec["rmv"] = rmv
+            if self.compat.compacted_table_strided_view and tables is not None and tables.shape[1] == M - 1:
+                # what the reference's kernels see: the [B, M] buffer (compacted columns + the
+                # untouched last column) read with a row pitch of M-1
+                full = torch.cat([tables, dm.block_tables[:, M - 1:M]], dim=1)
+                tables = full.flatten()[:tables.shape[0] * (M - 1)].view(tables.shape[0], M - 1).contiguous()
             dec["tables"] = tables
             if dec["rmv"] is not None:
                 dec["readback"] = staging.AsyncReadback(dec["rmv"])

@@ -147,10 +147,17 @@ class CompatFlags:
     # length shortened by one block - the victim block stays visible and the last block (with
     # the step's own token) is cut off.  The default attends the compacted table.
     streaming_decode_original_table: bool = False
+    # the compacted table HEAD hands to paged attention is the slice [:, :M-1] of an [B, M] tensor
+    # (torch_cuda_sdpa.py:1583), i.e. a view whose rows are M entries apart, and the attention
+    # kernels index it with size(1) = M-1 as the row pitch (csrc/attention/paged_attention_v1.cu:63,81,
+    # attention_kernels.cuh:207): row i is read from flat offset i*(M-1) of the underlying buffer,
+    # so on an eviction step every sequence but the first attends a table shifted by i entries
+    # that starts with other rows' block ids.  The default hands the kernel a dense table.
+    compacted_table_strided_view: bool = False
 
     @classmethod
     def reference_head(cls) -> "CompatFlags":
-        return cls(True, True, True, True, True, True, True, True)
+        return cls(True, True, True, True, True, True, True, True, True)
 
 
 @dataclass
