@@ -597,3 +597,120 @@ def test_sdpa_forward_golden(oracle):
         torch.testing.assert_close(got, ref, atol=2e-6, rtol=2e-6)
         n += 1
     assert n == 4
+
+
+def _backend_gen():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_backend",
+                                                  os.path.join(GOLDEN, "make_golden_backend.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _rel_close(got, ref, atol, what):
+    scale = max(1.0, float(ref.abs().max()))
+    torch.testing.assert_close(got / scale, ref / scale, atol=atol, rtol=1.6e-2, msg=lambda m: f"{what}: {m}")
+
+
+BACKEND_TRACES = json.load(open(os.path.join(GOLDEN, "backend_traces.json")))
+
+
+@pytest.mark.parametrize("trace", BACKEND_TRACES, ids=[t["name"] for t in BACKEND_TRACES])
+def test_backend_traces_oracle_walk(oracle, trace):
+    """The oracle's pieces, composed the way HEAD composes them, against end-to-end traces of the
+    reference's own TorchCUDASDPABackendImpl.forward (tests/golden/make_golden_backend.py): the KV
+    cache of every layer byte for byte after every step, every layer's victims, outputs within
+    tolerance.  HEAD's forms are all in play: cross-head re-packing of the token-level prompt prune,
+    random victims drawn per layer from one global stream, scores through the flat view of the
+    cache block and never deleted, the in-loop slice of the compacted table and its strided-view
+    read, streamingLLM attending the original table with the shortened length."""
+    import hashlib
+    import random
+    gen = _backend_gen()
+    zp = np.load(os.path.join(GOLDEN, "backend_traces_prefill.npz"))
+    zd = np.load(os.path.join(GOLDEN, "backend_traces_decode.npz"))
+    name, method, budget = trace["name"], trace["method"], trace["budget"]
+    Hq, Hkv, D, layers, nb = trace["Hq"], trace["Hkv"], trace["D"], trace["layers"], trace["num_blocks"]
+    prompts, seed, bs = trace["prompts"], trace["seed"], 16
+    B = len(prompts)
+    scale = D ** -0.5
+    x = 8
+    kc = [torch.zeros(nb, Hkv, D // x, bs, x, dtype=torch.bfloat16) for _ in range(layers)]
+    vc = [torch.zeros(nb, Hkv, D, bs, dtype=torch.bfloat16) for _ in range(layers)]
+
+    def cache_sha(li):
+        both = torch.stack([kc[li].reshape(nb, -1), vc[li].reshape(nb, -1)])
+        return hashlib.sha256(both.contiguous().view(torch.int16).numpy().tobytes()).hexdigest()
+
+    # ---- prefill
+    gp = trace["prefill"]
+    slots = torch.tensor(gp["slot_mapping"])
+    scores = [[None] * B for _ in range(layers)]
+    for li in range(layers):
+        q, k, v = gen.prompt_inputs(seed + li, prompts, Hq, Hkv, D)
+        q3, k3, v3 = q.view(-1, Hq, D), k.view(-1, Hkv, D), v.view(-1, Hkv, D)
+        pk, pv, off = [], [], 0
+        for n in prompts:
+            a, b = oracle.prompt_prune(k3[off:off + n], v3[off:off + n], method, budget, bs, compat_q2=True)
+            pk.append(a)
+            pv.append(b)
+            off += n
+        kept = [t.shape[0] for t in pk]
+        assert kept == gp["seq_kv_lens"]
+        oracle.reshape_and_cache(torch.cat(pk), torch.cat(pv), kc[li], vc[li], slots)
+        assert cache_sha(li) == gp["cache_sha"][li], (name, li)
+        if trace["disable_evict_prefill"]:
+            out = oracle.prefill_attention(q3.float(), k3.float(), v3.float(), prompts, prompts, scale)
+        else:
+            out = oracle.prefill_attention(q3.float(), torch.cat(pk).float(), torch.cat(pv).float(), prompts,
+                                           kept, scale)
+        ref = from_bits(zp[f"{name}_prefill_out{li}"], 2).float().view(-1, Hq, D)
+        _rel_close(out[::gen.PREFILL_ROW_STEP], ref, 2e-2, f"{name} prefill {li}")
+        for i in range(B):     # one score per full block of the pruned prompt (:1278-1288)
+            scores[li][i] = [oracle.block_score_formula(pk[i][b * bs:(b + 1) * bs].contiguous(),
+                                                        pv[i][b * bs:(b + 1) * bs].contiguous(),
+                                                        "value_l2").float().item() for b in range(kept[i] // bs)]
+    # ---- decode
+    rng = random.Random(1234)            # the global stream every layer's impl draws from (:796)
+    for step, gs in enumerate(trace["steps"]):
+        L, kv_adj, tables = gs["seq_lens"], gs["seq_kv_lens"], gs["tables"]
+        M = max(len(t) for t in tables)
+        bt = _padded(tables, M)
+        trig = [oracle.decode_trigger(L[i], budget, bs) for i in range(B)]
+        for li in range(layers):
+            q, k, v = gen.step_inputs(seed + 1000 * (step + 1) + li, B, Hq, Hkv, D)
+            zero, rmv = [], [-1] * B
+            if method in ("streamingLLM", "streamingLLM-1"):
+                rmv, zero = oracle.decode_streaming(L, tables, budget, bs, method)
+            elif method == "inverse_key_l2":
+                zero = oracle.decode_inverse_key_l2(L, tables, budget, bs, rng)
+            elif trace["random_evict"]:
+                for i in range(B):
+                    if trig[i]:
+                        end = 1 + 3 if method == "local" else len(tables[i]) - 1
+                        rmv[i] = rng.randint(1, end - 1)
+            else:
+                for i in range(B):
+                    if trig[i]:       # the decision precedes the step's KV write (:942-947)
+                        new = oracle.block_score(vc[li][tables[i][-1]], bs, Hkv, D, 2)
+                        rmv[i] = oracle.decode_topk_victim(scores[li][i], new, method, 3, False)
+            expect = {str(i): [f"r{i}", r] for i, r in enumerate(rmv) if r >= 0}
+            assert expect == gs["rmv_by_layer"][li], (name, step, li)
+            oracle.reshape_and_cache(k.view(B, Hkv, D), v.view(B, Hkv, D), kc[li], vc[li],
+                                     torch.tensor(gs["slot_mapping"]))
+            if zero:
+                z = torch.zeros(len(zero), Hkv, D, dtype=torch.bfloat16)
+                oracle.reshape_and_cache(z, z, kc[li], vc[li], torch.tensor(zero))
+            assert cache_sha(li) == gs["cache_sha"][li], (name, step, li)
+            key = f"{name}_s{step}_out{li}"
+            if key not in zd.files:
+                continue
+            use = bt
+            if method in ("global", "local") and any(r >= 0 for r in rmv):
+                q1 = oracle.compact_block_tables(bt, rmv, compat_q1=True)                 # [B, M-1]
+                full = torch.cat([q1, bt[:, M - 1:M]], dim=1)                             # the [B, M] buffer
+                use = full.flatten()[:B * (M - 1)].view(B, M - 1).contiguous()            # read with pitch M-1
+            out = oracle.paged_attention(q.view(B, Hq, D), kc[li], vc[li], use,
+                                         torch.tensor(kv_adj, dtype=torch.int32), scale)
+            _rel_close(out.float(), from_bits(zd[key], 2).float().view(B, Hq, D), 4e-3, f"{name} s{step} l{li}")
