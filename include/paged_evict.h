@@ -197,7 +197,12 @@ int pe_decode_step(void* out, const void* query, const void* new_key, const void
  * UNROTATED and are left as they are (the reference rotates them in place; nothing after
  * attention reads them); the rotated key row is what the cache receives.  positions int64
  * [num_seqs] (clamped to [0, max_position)), cos_sin_cache [max_position, rot_dim] of the storage
- * type (a row = rot_dim/2 cosines then rot_dim/2 sines), is_neox as in rotary_embedding.  The
+ * type (a row = rot_dim/2 cosines then rot_dim/2 sines), is_neox as in rotary_embedding.
+ * positions == NULL: cos_sin_cache is a per-step table [max_position >= num_seqs, rot_dim] whose
+ * row s belongs to sequence s (the rows of the model's table gathered by the step's positions,
+ * once for all layers): the kernel then requests the row together with the query instead of
+ * behind a dependent load of the position, which takes the rotation off the launch's start-up
+ * path.  The
  * arithmetic is that of pe_rope_reshape_and_cache (each product and their sum rounded to the
  * storage type), so the result and the cache bytes equal those of pe_rope_reshape_and_cache
  * followed by pe_paged_decode.  A sequence whose slot is negative is not cached, its query is

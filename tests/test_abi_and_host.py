@@ -75,9 +75,14 @@ def test_argument_checks_without_gpu():
     assert step_rope(128, 16, 48, 1) == 2 and b"rot_dim 48" in lib.pe_last_error()
     assert step_rope(256, 16, 128, 1) == 2 and b"head_size 256" in lib.pe_last_error()
     assert step_rope(128, 8, 128, 1) == 2 and b"MFMA decode path" in lib.pe_last_error()
-    assert lib.pe_decode_step_rope(p, p, p, p, p, p, p, p, p, None, None, p, 128, 1, 4096, 1, 32, 8, 128,
+    # (positions may be NULL - the per-step table form - so the missing pointer here is the table;
+    # a NULL positions with a table of fewer rows than sequences is refused as well)
+    assert lib.pe_decode_step_rope(p, p, p, p, p, p, p, p, p, None, p, None, 128, 1, 4096, 1, 32, 8, 128,
                                    16, 4, 4, 4096, 1024, 1024, 8192, 1024, 0.1, 32, 2, None, 0,
                                    None) == 1 and b"null pointer" in lib.pe_last_error()
+    assert lib.pe_decode_step_rope(p, p, p, p, p, p, p, p, p, None, None, p, 128, 1, 2, 3, 32, 8, 128,
+                                   16, 4, 4, 4096, 1024, 1024, 8192, 1024, 0.1, 32, 2, None, 0,
+                                   None) == 1 and b"one row per sequence" in lib.pe_last_error()
     bf = torch.bfloat16
     assert ops.decode_step_rope_supported(32, 8, 128, 16, bf, 128, True)
     assert ops.decode_step_rope_supported(32, 8, 128, 16, bf, 64, True)

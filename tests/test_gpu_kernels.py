@@ -906,6 +906,14 @@ def test_decode_step_rope(ops, oracle, dtype, is_neox, Hq, Hkv, D, rot, splits, 
                     max(lens))
     assert torch.equal(kc_2, kc_d) and torch.equal(vc_2, vc_d)
     assert torch.equal(out2, out)
+    # positions=None: the step's rows of the table handed over directly (what the layer launcher
+    # does once per step for all layers): same bits
+    kc_3, vc_3 = kc.cuda(), vc.cuda()
+    out3 = torch.empty_like(out)
+    step_cs = cs.cuda().index_select(0, pos.cuda())
+    ops.decode_step_rope(out3, None, qd, kd, vd, kc_3, vc_3, slots.cuda(), Hkv, sc, bt.cuda(), lens_t.cuda(),
+                         bs, max(lens), step_cs, is_neox)
+    assert torch.equal(out3, out) and torch.equal(kc_3, kc_d) and torch.equal(vc_3, vc_d)
 
 
 def test_device_diagnostics_report_clamps(oracle):

@@ -44,7 +44,7 @@ def time_graph(run, layers, iters=20):
 def main():
     dev = torch.device("cuda:0")
     bs, layers, max_pos = 16, 8, 8192
-    print("B Hq Hkv D kv | separate (rope + decode_step) | fused decode_step_rope | decode_step alone  (us per layer)")
+    print("B Hq Hkv D kv | separate (rope + decode_step) | fused, positions | fused, per-step table | decode_step alone  (us per layer)")
     for B, Hq, Hkv, D, kv in SHAPES:
         nblk = (kv + bs - 1) // bs
         nb = B * nblk + 8
@@ -75,13 +75,20 @@ def main():
             kc, vc = caches[i % layers]
             ops.decode_step_rope(out, pos, q, k, v, kc, vc, slots, Hkv, D ** -0.5, bt, lens, bs, kv, cs, True)
 
+        step_cs = cs.index_select(0, pos)
+
+        def fused_step_table(i):
+            q, k, v = views(i)
+            kc, vc = caches[i % layers]
+            ops.decode_step_rope(out, None, q, k, v, kc, vc, slots, Hkv, D ** -0.5, bt, lens, bs, kv, step_cs, True)
+
         def plain(i):
             q, k, v = views(i)
             kc, vc = caches[i % layers]
             ops.decode_step(out, q, k, v, kc, vc, slots, Hkv, D ** -0.5, bt, lens, bs, kv)
 
-        t_sep, t_fused, t_plain = (time_graph(f, layers) for f in (separate, fused, plain))
-        print(f"{B} {Hq} {Hkv} {D} {kv} | {t_sep:8.2f} | {t_fused:8.2f} | {t_plain:8.2f}", flush=True)
+        t_sep, t_fused, t_tab, t_plain = (time_graph(f, layers) for f in (separate, fused, fused_step_table, plain))
+        print(f"{B} {Hq} {Hkv} {D} {kv} | {t_sep:8.2f} | {t_fused:8.2f} | {t_tab:8.2f} | {t_plain:8.2f}", flush=True)
 
 
 if __name__ == "__main__":

@@ -174,8 +174,14 @@ void paged_decode_mfma_kernel(
   // chunk's adjacent pairs.  The loops are unrolled over every hs the head size admits, so all
   // fragment indices are constants.
   auto rope_load = [&](u32x4 (&cs)[KS]) {
-    int64_t pos = rope_positions[seq];
-    pos = pos < 0 ? 0 : (pos >= rope_max_position ? rope_max_position - 1 : pos);
+    // positions == nullptr: the table already holds one row per sequence of this launch (gathered
+    // once per step for all layers), so the cosines and sines are requested together with Q
+    // instead of behind a dependent load of the position
+    int64_t pos = seq;
+    if (rope_positions != nullptr) {
+      pos = rope_positions[seq];
+      pos = pos < 0 ? 0 : (pos >= rope_max_position ? rope_max_position - 1 : pos);
+    }
     const T* cs_row = rope_cos_sin + pos * rot_dim;
     const int half = rot_dim / 2;
 #pragma unroll
@@ -878,8 +884,11 @@ int pe_decode_step_rope(void* out, const void* query, const void* new_key, const
                         int max_seq_len, int dtype, void* workspace, int64_t workspace_bytes,
                         void* stream) {
   using namespace pe;
-  PE_REQUIRE(num_seqs == 0 || (new_key && new_value && slot_mapping && positions && cos_sin_cache),
+  PE_REQUIRE(num_seqs == 0 || (new_key && new_value && slot_mapping && cos_sin_cache),
              PE_ERR_INVALID_ARG, "decode_step_rope: null pointer");
+  PE_REQUIRE(positions != nullptr || max_position >= num_seqs, PE_ERR_INVALID_ARG,
+             "decode_step_rope: without positions the table needs one row per sequence (%lld < %d)",
+             (long long)max_position, num_seqs);
   PE_REQUIRE(new_k_stride % 8 == 0 && new_v_stride % 8 == 0 &&
                  (((uintptr_t)new_key | (uintptr_t)new_value | (uintptr_t)cos_sin_cache) % 16 == 0),
              PE_ERR_INVALID_ARG, "decode_step_rope: rows must be 16-byte aligned");

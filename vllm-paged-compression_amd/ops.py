@@ -715,7 +715,8 @@ def decode_step_rope(out, positions, query, key, value, key_cache, value_cache, 
     """Rotary embedding of the step's query/key rows + KV write + paged attention in ONE launch
     (see pe_decode_step_rope): what ``rotary_embedding`` followed by ``decode_step`` computes,
     except that ``query`` and ``key`` are given unrotated and stay as they are.  positions int64
-    [S], cos_sin_cache [max_position, rot_dim] of the query dtype."""
+    [S], cos_sin_cache [max_position, rot_dim] of the query dtype; ``positions=None``:
+    cos_sin_cache holds the step's rows already, row s for sequence s."""
     dev = _need_gpu(out, positions, query, key, value, key_cache, value_cache, slot_mapping,
                     block_tables, seq_lens, cos_sin_cache)
     S, Hq, D = query.shape
@@ -727,7 +728,10 @@ def decode_step_rope(out, positions, query, key, value, key_cache, value_cache, 
             raise RuntimeError("decode_step_rope: dense rows of the cache dtype expected")
     if slot_mapping.dtype != torch.int64 or slot_mapping.numel() != S or not slot_mapping.is_contiguous():
         raise RuntimeError("decode_step_rope: slot_mapping must be contiguous int64[num_seqs]")
-    if positions.dtype != torch.int64 or positions.numel() != S or not positions.is_contiguous():
+    if positions is None:
+        if cos_sin_cache.dim() != 2 or cos_sin_cache.shape[0] < S:
+            raise RuntimeError("decode_step_rope: without positions cos_sin_cache must hold one row per sequence")
+    elif positions.dtype != torch.int64 or positions.numel() != S or not positions.is_contiguous():
         raise RuntimeError("decode_step_rope: positions must be contiguous int64[num_seqs]")
     if cos_sin_cache.dim() != 2 or not cos_sin_cache.is_contiguous() or cos_sin_cache.dtype != query.dtype:
         raise RuntimeError("decode_step_rope: cos_sin_cache [max_position, rot_dim] of the query dtype expected")
@@ -832,6 +836,7 @@ class DecodeLayerLauncher:
         self._fr_rest = _prewrap(lib.pe_decode_step_rope, 15, self._fs_tail[4:])
         self._rope_geom = (num_heads, num_kv_heads, head_size, bs, S)
         self._rope_ok = {}   # (rot_dim, is_neox) -> whether the rotating launch serves it
+        self._step_cs = self._step_cs_key = None   # this step's rows of the cos/sin table
         self._rc_tail = _prewrap(lib.pe_reshape_and_cache, 4, self._rc_tail)
         self._pa_tail = _prewrap(lib.pe_paged_decode, 4, self._pa_tail)
         self._fs_tail = _prewrap(lib.pe_decode_step, 6, self._fs_tail)
@@ -879,10 +884,16 @@ class DecodeLayerLauncher:
                 if sink is not None:
                     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     s.record()
+                # all layers of the step rotate by the same positions: their rows of the model's
+                # table are gathered once (first layer) and handed to the kernel without positions
+                step_cs = self._step_cs
+                if step_cs is None or self._step_cs_key != (positions.data_ptr(), cos_sin.data_ptr()):
+                    step_cs = cos_sin.index_select(0, positions.clamp(0, cos_sin.shape[0] - 1))
+                    self._step_cs, self._step_cs_key = step_cs, (positions.data_ptr(), cos_sin.data_ptr())
                 _lib.check(lib.pe_decode_step_rope(
                     out.data_ptr(), query.data_ptr(), key.data_ptr(), value.data_ptr(), kc, vc,
-                    *self._fr_head, positions.data_ptr(), cos_sin.data_ptr(), cos_sin.shape[1],
-                    1 if is_neox else 0, cos_sin.shape[0], *self._fr_rest), "decode_step_rope")
+                    *self._fr_head, None, step_cs.data_ptr(), cos_sin.shape[1],
+                    1 if is_neox else 0, S, *self._fr_rest), "decode_step_rope")
                 if sink is not None:
                     e.record()
                     sink.append((s, e))
