@@ -57,9 +57,10 @@ def test_backend_reproduces_reference_forward(trace):
     from vllm_paged_compression_amd.config import CacheConfigView, CompatFlags, PagedEvictConfig
     from vllm_paged_compression_amd.page_evict_kv_util import adjust_seq_kv_len
     gen = _gen()
-    zp = np.load(os.path.join(GOLDEN, "backend_traces_prefill.npz"))
-    zd = np.load(os.path.join(GOLDEN, "backend_traces_decode.npz"))
     name, method, budget = trace["name"], trace["method"], trace["budget"]
+    tag = "_llama" if name.startswith("llama_") else ""
+    zp = np.load(os.path.join(GOLDEN, f"backend_traces{tag}_prefill.npz"))
+    zd = np.load(os.path.join(GOLDEN, f"backend_traces{tag}_decode.npz"))
     Hq, Hkv, D, layers, nb = trace["Hq"], trace["Hkv"], trace["D"], trace["layers"], trace["num_blocks"]
     prompts, seed = trace["prompts"], trace["seed"]
     cfg = PagedEvictConfig(trace["disable_evict_prefill"], "budget", method, budget, 3)
@@ -94,13 +95,17 @@ def test_backend_reproduces_reference_forward(trace):
              for i, n in enumerate(prompts)]
     meta = builder(inter).build(list(prompts), list(prompts), -1, len(prompts))
     assert meta.slot_mapping.cpu().tolist() == gp["slot_mapping"]
-    step_rows = gen.PREFILL_ROW_STEP
+    step_rows = trace["prefill_row_step"]
     for li in range(layers):
-        q, k, v = gen.prompt_inputs(seed + li, prompts, Hq, Hkv, D)
+        if trace["plain_prompts"]:
+            q, k, v = gen.step_inputs(seed + li, sum(prompts), Hq, Hkv, D)
+        else:
+            q, k, v = gen.prompt_inputs(seed + li, prompts, Hq, Hkv, D)
         out = impls[li].forward(q.cuda(), k.cuda(), v.cuda(), kv[li], meta)
         assert _sha(kv[li]) == gp["cache_sha"][li], (name, "prefill cache", li)
-        ref = from_bits(zp[f"{name}_prefill_out{li}"], 2).float()
-        _close(out[::step_rows].cpu().float(), ref, 2e-2, f"{name} prefill layer {li}")
+        if f"{name}_prefill_out{li}" in zp.files:
+            ref = from_bits(zp[f"{name}_prefill_out{li}"], 2).float()
+            _close(out[::step_rows].cpu().float(), ref, 2e-2, f"{name} prefill layer {li}")
     assert impls[0].get_rmv_block_idx() == {}
 
     # ---- decode

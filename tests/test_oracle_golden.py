@@ -628,9 +628,10 @@ def test_backend_traces_oracle_walk(oracle, trace):
     import hashlib
     import random
     gen = _backend_gen()
-    zp = np.load(os.path.join(GOLDEN, "backend_traces_prefill.npz"))
-    zd = np.load(os.path.join(GOLDEN, "backend_traces_decode.npz"))
     name, method, budget = trace["name"], trace["method"], trace["budget"]
+    tag = "_llama" if name.startswith("llama_") else ""
+    zp = np.load(os.path.join(GOLDEN, f"backend_traces{tag}_prefill.npz"))
+    zd = np.load(os.path.join(GOLDEN, f"backend_traces{tag}_decode.npz"))
     Hq, Hkv, D, layers, nb = trace["Hq"], trace["Hkv"], trace["D"], trace["layers"], trace["num_blocks"]
     prompts, seed, bs = trace["prompts"], trace["seed"], 16
     B = len(prompts)
@@ -648,7 +649,10 @@ def test_backend_traces_oracle_walk(oracle, trace):
     slots = torch.tensor(gp["slot_mapping"])
     scores = [[None] * B for _ in range(layers)]
     for li in range(layers):
-        q, k, v = gen.prompt_inputs(seed + li, prompts, Hq, Hkv, D)
+        if trace["plain_prompts"]:
+            q, k, v = gen.step_inputs(seed + li, sum(prompts), Hq, Hkv, D)
+        else:
+            q, k, v = gen.prompt_inputs(seed + li, prompts, Hq, Hkv, D)
         q3, k3, v3 = q.view(-1, Hq, D), k.view(-1, Hkv, D), v.view(-1, Hkv, D)
         pk, pv, off = [], [], 0
         for n in prompts:
@@ -660,13 +664,16 @@ def test_backend_traces_oracle_walk(oracle, trace):
         assert kept == gp["seq_kv_lens"]
         oracle.reshape_and_cache(torch.cat(pk), torch.cat(pv), kc[li], vc[li], slots)
         assert cache_sha(li) == gp["cache_sha"][li], (name, li)
-        if trace["disable_evict_prefill"]:
-            out = oracle.prefill_attention(q3.float(), k3.float(), v3.float(), prompts, prompts, scale)
-        else:
-            out = oracle.prefill_attention(q3.float(), torch.cat(pk).float(), torch.cat(pv).float(), prompts,
-                                           kept, scale)
-        ref = from_bits(zp[f"{name}_prefill_out{li}"], 2).float().view(-1, Hq, D)
-        _rel_close(out[::gen.PREFILL_ROW_STEP], ref, 2e-2, f"{name} prefill {li}")
+        if f"{name}_prefill_out{li}" in zp.files and sum(prompts) <= 1024:
+            # (the scalar C attention over the 4 x 1024-token prompts of the large-geometry traces
+            # would take minutes: there the GPU test compares the prefill outputs)
+            if trace["disable_evict_prefill"]:
+                out = oracle.prefill_attention(q3.float(), k3.float(), v3.float(), prompts, prompts, scale)
+            else:
+                out = oracle.prefill_attention(q3.float(), torch.cat(pk).float(), torch.cat(pv).float(), prompts,
+                                               kept, scale)
+            ref = from_bits(zp[f"{name}_prefill_out{li}"], 2).float().view(-1, Hq, D)
+            _rel_close(out[::trace["prefill_row_step"]], ref, 2e-2, f"{name} prefill {li}")
         for i in range(B):     # one score per full block of the pruned prompt (:1278-1288)
             scores[li][i] = [oracle.block_score_formula(pk[i][b * bs:(b + 1) * bs].contiguous(),
                                                         pv[i][b * bs:(b + 1) * bs].contiguous(),
