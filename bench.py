@@ -123,6 +123,11 @@ def parse():
                          "the backend, which rotates a decode layer's rows inside the attention launch "
                          "(pe_decode_step_rope).  off (default) = the headline workload, rows arrive "
                          "rotated")
+    ap.add_argument("--reference-head-compat", action="store_true",
+                    help="run with every switch that reproduces the reference's HEAD "
+                         "(config.CompatFlags.reference_head(): a decision per layer with random victims, "
+                         "the in-loop table slice and its strided read, unfused KV write, ...) instead of "
+                         "the intended semantics the headline is measured on")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--alt-evict", type=float, default=0.5,
                     help="second eviction fraction measured after the timed region and reported under "
@@ -176,9 +181,13 @@ class Workload:
         self.num_blocks = B * self.blocks_per_seq + 8
         shape = PagedEvictBackend.get_kv_cache_shape(self.num_blocks, self.bs, self.Hkv, self.D)
         self.kv = [torch.zeros(shape, dtype=self.dtype, device=dev) for _ in range(a.layers)]
+        compat = None
+        if a.reference_head_compat:
+            from vllm_paged_compression_amd.config import CompatFlags
+            compat = CompatFlags.reference_head()
         self.impls = [PagedEvictBackend.get_impl_cls()(
             self.Hq, self.D, self.D ** -0.5, self.Hkv, None, None, "auto", None, None,
-            cache_config=self.ccfg, prefix=f"model.layers.{i}.self_attn.attn",
+            cache_config=self.ccfg, prefix=f"model.layers.{i}.self_attn.attn", compat=compat,
             prompt_evict_method=(a.prompt_evict_method
                                  if self.cfg is not None and not self.percentage else None),
             tp_group=tp_group, total_num_kv_heads=a.num_kv_heads,
@@ -325,7 +334,8 @@ class Workload:
         B, L0 = a.num_prompts, a.input_len
         sched = BatchEvictionScheduler(bs, self.num_blocks, self.cfg, max_seqs=B,
                                        max_blocks_per_seq=self.blocks_per_seq_full + 2,
-                                       device=None if a.host_tables else self.dev)
+                                       device=None if (a.host_tables or a.reference_head_compat)
+                                       else self.dev)
         rids = [f"req{i}" for i in range(B)]
         for i, r in enumerate(rids):
             sched.add_request(r, i, L0)
@@ -704,6 +714,7 @@ def main():
             "dist_backend": (dist.get_backend() if world > 1 else None),
             "devices": devices,
             "oproj_allreduce": bool(wl.allreduce), "rope": a.rope,
+            "reference_head_compat": bool(a.reference_head_compat),
             "graph_decode": bool(a.graph_decode and not a.host_tables and not wl.allreduce
                                  and not wl.percentage and a.rope == "off"), **kv},
     }
