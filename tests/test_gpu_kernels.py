@@ -536,6 +536,23 @@ def test_prefill_reference_sdpa_forward_golden(ops):
     assert n == 4
 
 
+def test_prefill_tile_shapes_same_bits(ops):
+    """pe_prefill_causal picks its tile shape from the declared maximum prompt length and the
+    number of 256-row tiles (16 rows x 8 waves up to 512 tokens, 32 x 8 from 2048 tokens with
+    >= 2048 tiles, 32 x 4 otherwise); max_q_len is an upper bound, so declaring a larger one
+    moves the same data through each shape: the outputs must not differ in a single bit."""
+    g = torch.Generator().manual_seed(12)
+    Hq, Hkv, D = 32, 8, 128
+    q_lens = [300, 512, 17, 129, 256, 1, 400, 333]
+    kv_lens = [300, 384, 17, 129, 256, 1, 208, 333]
+    q = (torch.rand(sum(q_lens), Hq, D, generator=g) * 2 - 1).to(torch.bfloat16).cuda()
+    k = (torch.rand(sum(kv_lens), Hkv, D, generator=g) * 2 - 1).to(torch.bfloat16).cuda()
+    v = (torch.rand(sum(kv_lens), Hkv, D, generator=g) * 2 - 1).to(torch.bfloat16).cuda()
+    cq, ck = _cu(q_lens).cuda(), _cu(kv_lens).cuda()
+    outs = [ops.prefill_causal(q, k, v, cq, ck, m, D ** -0.5) for m in (512, 1024, 2048)]
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
 def test_prefill_matches_torch_sdpa_top_left(ops):
     """The mask alignment is the one torch SDPA(is_causal=True) uses for L_q != L_kv."""
     g = torch.Generator().manual_seed(4)

@@ -442,12 +442,28 @@ extern "C" int pe_prefill_causal(void* out, const void* q, const void* k, const 
                     out_stride % 8 == 0 &&
                     (((uintptr_t)out | (uintptr_t)q | (uintptr_t)k | (uintptr_t)v) % 16 == 0);
   if (mfma) {
-    // tile shape: PE_PREFILL_SHAPE=<NR><WAVES> picks rows-per-wave / waves-per-workgroup
-    // (24 = 32 rows x 4 waves, 18 = 16 x 8, 28 = 32 x 8, 14 = 16 x 4) for tuning runs
-    static const int shape = [] {
+    // Tile shape <NR><WAVES> = rows per wave / waves per workgroup: 24 = 32 rows x 4 waves (128-row
+    // workgroups, two per CU), 18 = 16 x 8 (128 rows, four waves per SIMD), 28 = 32 x 8 (256 rows,
+    // one workgroup per CU), 14 = 16 x 4.  All give the same bits.  Measured on MI355X (32 query /
+    // 8 KV heads x 128 unless noted, us per launch, 24 / 18 / 28): 32 x 256 tokens 53.8 / 49.4 / 69.3;
+    // 16 x 512 70.4 / 68.0 / 83.8 (12 heads x 64: 20.9 / 19.5 / 21.4); 8 x 1024 100 / 104 / 117;
+    // 8 x 1536 200 / 212 / 220; 8 x 2048 381 / - / 378; 8 x 4096 1243 / - / 1221; 8 x 8192 4238 / - / 4073;
+    // 1 x 32768 7572 / - / 7292; 8 x 4096 with 8 query heads on 1 KV head 320 / 351 / 326.  So:
+    // short prompts take the four-waves-per-SIMD shape (their workgroups are mostly start-up and
+    // diagonal tiles, which more resident waves hide better), long prompts with enough 256-row
+    // tiles to fill the chip several times over take the 256-row shape (half the K/V tile traffic
+    // per flop), everything else the 128-row default.  PE_PREFILL_SHAPE overrides (tuning runs).
+    static const int shape_env = [] {
       const char* e = getenv("PE_PREFILL_SHAPE");
-      return e ? atoi(e) : PF_DEFAULT_SHAPE;
+      return e ? atoi(e) : 0;
     }();
+    int shape = shape_env;
+    if (shape == 0) {
+      const int64_t tiles256 = (int64_t)num_seqs * num_heads * ((max_q_len + 255) / 256);
+      if (max_q_len <= 512) shape = 18;
+      else if (max_q_len >= 2048 && tiles256 >= 2048) shape = 28;
+      else shape = PF_DEFAULT_SHAPE;
+    }
     const float sl2 = scale * 1.4426950408889634f;
 #define PE_LAUNCH_PF(T, HS, NR, WAVES, WPE)                                                        \
   do {                                                                                             \
