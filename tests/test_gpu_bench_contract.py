@@ -11,7 +11,8 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("extra", [[], ["--cache-prune-type", "percentage", "--evict-freq", "2"]])
+@pytest.mark.parametrize("extra", [[], ["--cache-prune-type", "percentage", "--evict-freq", "2"],
+                                   ["--reference-head-compat"]])
 def test_bench_json_line(extra):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1",
            "--num-prompts", "8", "--prefill-batch", "4", "--output-len", "24", "--layers", "4",
@@ -98,3 +99,23 @@ def test_bench_graph_decode_leaves_the_same_kv_cache(extra):
     assert res[0]["graph_decode"] is False and res[1]["graph_decode"] is True
     assert res[0]["kv_checksum"] == res[1]["kv_checksum"] != 0
     assert res[0]["kv_gb_held_peak"] == res[1]["kv_gb_held_peak"]
+
+
+@pytest.mark.parametrize("mode", ["separate", "fused"])
+def test_bench_rope_modes(mode):
+    """--rope separate / fused count the model's rotary embedding in (a launch of its own in
+    front of attention, or inside the decode-attention launch).  The bench rotates its reused
+    synthetic rows in place, so the two runs do not hold comparable data: that the two forms
+    write the same bits is checked on fresh data in tests/test_gpu_kernels.py::test_decode_step_rope
+    and tests/test_gpu_backend.py::test_backend_forward_with_rope; here only the line."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0",
+           "--num-prompts", "4", "--prefill-batch", "4", "--input-len", "200", "--output-len", "40",
+           "--layers", "3", "--no-cpu-baseline", "--alt-evict", "0", "--rope", mode]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=280, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["config"]["rope"] == mode and d["value"] > 0
+    if mode == "fused":
+        assert "rotary" in d["roofline"]["includes"]
+    else:
+        assert d.get("roofline") is None  # launches of two kernels alternate: no per-kernel span
