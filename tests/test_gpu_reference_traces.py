@@ -58,20 +58,23 @@ def test_backend_reproduces_reference_forward(trace):
     from vllm_paged_compression_amd.page_evict_kv_util import adjust_seq_kv_len
     gen = _gen()
     name, method, budget = trace["name"], trace["method"], trace["budget"]
-    tag = "_llama" if name.startswith("llama_") else ""
+    tag = "_llama" if name.startswith("llama_") else "_full" if name.startswith("full_") else ""
+    dt, code = {"bf16": (torch.bfloat16, 2), "fp16": (torch.float16, 1)}[trace["dtype"]]
     zp = np.load(os.path.join(GOLDEN, f"backend_traces{tag}_prefill.npz"))
     zd = np.load(os.path.join(GOLDEN, f"backend_traces{tag}_decode.npz"))
     Hq, Hkv, D, layers, nb = trace["Hq"], trace["Hkv"], trace["D"], trace["layers"], trace["num_blocks"]
     prompts, seed = trace["prompts"], trace["seed"]
-    cfg = PagedEvictConfig(trace["disable_evict_prefill"], "budget", method, budget, 3)
-    assert cfg.cache_budget == budget
+    cfg = None                  # method None: paged eviction off, the full-cache baseline
+    if method is not None:
+        cfg = PagedEvictConfig(trace["disable_evict_prefill"], "budget", method, budget, 3)
+        assert cfg.cache_budget == budget
     compat = CompatFlags.reference_head()
     compat.random_victim = bool(trace["random_evict"])
     cache_cfg = CacheConfigView(BS, cfg)
     impl_cls = PagedEvictBackend.get_impl_cls()
     impls = [impl_cls(Hq, D, D ** -0.5, Hkv, None, None, "auto", None, None, cache_config=cache_cfg,
                       prefix=f"model.layers.{i}.self_attn.attn", compat=compat) for i in range(layers)]
-    kv = [torch.zeros(PagedEvictBackend.get_kv_cache_shape(nb, BS, Hkv, D), dtype=torch.bfloat16, device="cuda")
+    kv = [torch.zeros(PagedEvictBackend.get_kv_cache_shape(nb, BS, Hkv, D), dtype=dt, device="cuda")
           for _ in range(layers)]
     sched = EvictionScheduler(EvictBlockSpaceManager(BS, nb, cfg, watermark=0.0))
     bm = sched.block_manager
@@ -98,13 +101,13 @@ def test_backend_reproduces_reference_forward(trace):
     step_rows = trace["prefill_row_step"]
     for li in range(layers):
         if trace["plain_prompts"]:
-            q, k, v = gen.step_inputs(seed + li, sum(prompts), Hq, Hkv, D)
+            q, k, v = gen.step_inputs(seed + li, sum(prompts), Hq, Hkv, D, dt)
         else:
-            q, k, v = gen.prompt_inputs(seed + li, prompts, Hq, Hkv, D)
+            q, k, v = gen.prompt_inputs(seed + li, prompts, Hq, Hkv, D, dt)
         out = impls[li].forward(q.cuda(), k.cuda(), v.cuda(), kv[li], meta)
         assert _sha(kv[li]) == gp["cache_sha"][li], (name, "prefill cache", li)
         if f"{name}_prefill_out{li}" in zp.files:
-            ref = from_bits(zp[f"{name}_prefill_out{li}"], 2).float()
+            ref = from_bits(zp[f"{name}_prefill_out{li}"], code).float()
             _close(out[::step_rows].cpu().float(), ref, 2e-2, f"{name} prefill layer {li}")
     assert impls[0].get_rmv_block_idx() == {}
 
@@ -127,14 +130,14 @@ def test_backend_reproduces_reference_forward(trace):
         meta = builder(inter).build(list(logical), [1] * len(prompts), -1, len(prompts))
         assert meta.slot_mapping.cpu().tolist() == gs["slot_mapping"], (name, step)
         for li in range(layers):
-            q, k, v = gen.step_inputs(seed + 1000 * (step + 1) + li, len(prompts), Hq, Hkv, D)
+            q, k, v = gen.step_inputs(seed + 1000 * (step + 1) + li, len(prompts), Hq, Hkv, D, dt)
             out = impls[li].forward(q.cuda(), k.cuda(), v.cuda(), kv[li], meta)
             got = {str(i): [r, int(b)] for i, (r, b) in impls[li].get_rmv_block_idx().items()}
             assert got == gs["rmv_by_layer"][li], (name, step, li)
             assert _sha(kv[li]) == gs["cache_sha"][li], (name, step, li)
             key = f"{name}_s{step}_out{li}"
             if key in zd.files:
-                ref = from_bits(zd[key], 2).float()
+                ref = from_bits(zd[key], code).float()
                 _close(out.cpu().float(), ref, 4e-3, f"{name} step {step} layer {li}")
         rmv = impls[0].get_rmv_block_idx()
         evictions += len(rmv)

@@ -629,16 +629,19 @@ def test_backend_traces_oracle_walk(oracle, trace):
     import random
     gen = _backend_gen()
     name, method, budget = trace["name"], trace["method"], trace["budget"]
-    tag = "_llama" if name.startswith("llama_") else ""
+    tag = "_llama" if name.startswith("llama_") else "_full" if name.startswith("full_") else ""
     zp = np.load(os.path.join(GOLDEN, f"backend_traces{tag}_prefill.npz"))
     zd = np.load(os.path.join(GOLDEN, f"backend_traces{tag}_decode.npz"))
     Hq, Hkv, D, layers, nb = trace["Hq"], trace["Hkv"], trace["D"], trace["layers"], trace["num_blocks"]
     prompts, seed, bs = trace["prompts"], trace["seed"], 16
+    dt, code = {"bf16": (torch.bfloat16, 2), "fp16": (torch.float16, 1)}[trace["dtype"]]
+    if method is None:
+        budget = 1 << 30        # paged eviction off (the :861-863 arm of forward): nothing is ever pruned
     B = len(prompts)
     scale = D ** -0.5
     x = 8
-    kc = [torch.zeros(nb, Hkv, D // x, bs, x, dtype=torch.bfloat16) for _ in range(layers)]
-    vc = [torch.zeros(nb, Hkv, D, bs, dtype=torch.bfloat16) for _ in range(layers)]
+    kc = [torch.zeros(nb, Hkv, D // x, bs, x, dtype=dt) for _ in range(layers)]
+    vc = [torch.zeros(nb, Hkv, D, bs, dtype=dt) for _ in range(layers)]
 
     def cache_sha(li):
         both = torch.stack([kc[li].reshape(nb, -1), vc[li].reshape(nb, -1)])
@@ -650,13 +653,14 @@ def test_backend_traces_oracle_walk(oracle, trace):
     scores = [[None] * B for _ in range(layers)]
     for li in range(layers):
         if trace["plain_prompts"]:
-            q, k, v = gen.step_inputs(seed + li, sum(prompts), Hq, Hkv, D)
+            q, k, v = gen.step_inputs(seed + li, sum(prompts), Hq, Hkv, D, dt)
         else:
-            q, k, v = gen.prompt_inputs(seed + li, prompts, Hq, Hkv, D)
+            q, k, v = gen.prompt_inputs(seed + li, prompts, Hq, Hkv, D, dt)
         q3, k3, v3 = q.view(-1, Hq, D), k.view(-1, Hkv, D), v.view(-1, Hkv, D)
         pk, pv, off = [], [], 0
         for n in prompts:
-            a, b = oracle.prompt_prune(k3[off:off + n], v3[off:off + n], method, budget, bs, compat_q2=True)
+            a, b = oracle.prompt_prune(k3[off:off + n], v3[off:off + n], method or "streamingLLM", budget, bs,
+                                       compat_q2=True)
             pk.append(a)
             pv.append(b)
             off += n
@@ -672,7 +676,7 @@ def test_backend_traces_oracle_walk(oracle, trace):
             else:
                 out = oracle.prefill_attention(q3.float(), torch.cat(pk).float(), torch.cat(pv).float(), prompts,
                                                kept, scale)
-            ref = from_bits(zp[f"{name}_prefill_out{li}"], 2).float().view(-1, Hq, D)
+            ref = from_bits(zp[f"{name}_prefill_out{li}"], code).float().view(-1, Hq, D)
             _rel_close(out[::trace["prefill_row_step"]], ref, 2e-2, f"{name} prefill {li}")
         for i in range(B):     # one score per full block of the pruned prompt (:1278-1288)
             scores[li][i] = [oracle.block_score_formula(pk[i][b * bs:(b + 1) * bs].contiguous(),
@@ -686,9 +690,11 @@ def test_backend_traces_oracle_walk(oracle, trace):
         bt = _padded(tables, M)
         trig = [oracle.decode_trigger(L[i], budget, bs) for i in range(B)]
         for li in range(layers):
-            q, k, v = gen.step_inputs(seed + 1000 * (step + 1) + li, B, Hq, Hkv, D)
+            q, k, v = gen.step_inputs(seed + 1000 * (step + 1) + li, B, Hq, Hkv, D, dt)
             zero, rmv = [], [-1] * B
-            if method in ("streamingLLM", "streamingLLM-1"):
+            if method is None:
+                pass
+            elif method in ("streamingLLM", "streamingLLM-1"):
                 rmv, zero = oracle.decode_streaming(L, tables, budget, bs, method)
             elif method == "inverse_key_l2":
                 zero = oracle.decode_inverse_key_l2(L, tables, budget, bs, rng)
@@ -707,7 +713,7 @@ def test_backend_traces_oracle_walk(oracle, trace):
             oracle.reshape_and_cache(k.view(B, Hkv, D), v.view(B, Hkv, D), kc[li], vc[li],
                                      torch.tensor(gs["slot_mapping"]))
             if zero:
-                z = torch.zeros(len(zero), Hkv, D, dtype=torch.bfloat16)
+                z = torch.zeros(len(zero), Hkv, D, dtype=dt)
                 oracle.reshape_and_cache(z, z, kc[li], vc[li], torch.tensor(zero))
             assert cache_sha(li) == gs["cache_sha"][li], (name, step, li)
             key = f"{name}_s{step}_out{li}"
@@ -720,4 +726,4 @@ def test_backend_traces_oracle_walk(oracle, trace):
                 use = full.flatten()[:B * (M - 1)].view(B, M - 1).contiguous()            # read with pitch M-1
             out = oracle.paged_attention(q.view(B, Hq, D), kc[li], vc[li], use,
                                          torch.tensor(kv_adj, dtype=torch.int32), scale)
-            _rel_close(out.float(), from_bits(zd[key], 2).float().view(B, Hq, D), 4e-3, f"{name} s{step} l{li}")
+            _rel_close(out.float(), from_bits(zd[key], code).float().view(B, Hq, D), 4e-3, f"{name} s{step} l{li}")
