@@ -46,7 +46,14 @@ def _close(got, ref, atol, what):
                                msg=lambda m: f"{what}: {m}")
 
 
-TRACES = json.load(open(os.path.join(GOLDEN, "backend_traces.json")))
+# staged_scored_local is HEAD with its hard-coded random victims switched off AND requests admitted
+# over two prefill steps: there the reference's manager forgets the first group's scores at the
+# second prefill step, restarts them from zeros and scores the just-filled block of ANOTHER
+# request's table (block_l2norm_manager.py:34-61, torch_cuda_sdpa.py:1520).  The backend keeps a
+# sequence's scores while it runs and scores its own block; that combination is held to the trace
+# by the oracle walk only (tests/test_oracle_golden.py::test_backend_traces_oracle_walk).
+TRACES = [t for t in json.load(open(os.path.join(GOLDEN, "backend_traces.json")))
+          if t["name"] != "staged_scored_local"]
 
 
 @pytest.mark.parametrize("trace", TRACES, ids=[t["name"] for t in TRACES])
@@ -58,7 +65,7 @@ def test_backend_reproduces_reference_forward(trace):
     from vllm_paged_compression_amd.page_evict_kv_util import adjust_seq_kv_len
     gen = _gen()
     name, method, budget = trace["name"], trace["method"], trace["budget"]
-    tag = "_llama" if name.startswith("llama_") else "_full" if name.startswith("full_") else ""
+    tag = next(("_" + g for g in ("llama", "full", "staged") if name.startswith(g + "_")), "")
     dt, code = {"bf16": (torch.bfloat16, 2), "fp16": (torch.float16, 1)}[trace["dtype"]]
     zp = np.load(os.path.join(GOLDEN, f"backend_traces{tag}_prefill.npz"))
     zd = np.load(os.path.join(GOLDEN, f"backend_traces{tag}_decode.npz"))
@@ -79,8 +86,6 @@ def test_backend_reproduces_reference_forward(trace):
     sched = EvictionScheduler(EvictBlockSpaceManager(BS, nb, cfg, watermark=0.0))
     bm = sched.block_manager
     rids = [f"r{i}" for i in range(len(prompts))]
-    for i, n in enumerate(prompts):
-        sched.add_request(rids[i], i, n)
 
     def builder(inter):
         runner = SimpleNamespace(device=torch.device("cuda:0"), cache_config=cache_cfg, pin_memory=False)
@@ -88,36 +93,49 @@ def test_backend_reproduces_reference_forward(trace):
                              inter_data_list=inter)
         return PagedEvictBackend.make_metadata_builder(ib)
 
-    # ---- prefill
-    gp = trace["prefill"]
-    assert [list(bm.get_block_table(i)) for i in range(len(prompts))] == gp["tables"]
-    assert [bm.get_seq_kv_len(i) for i in range(len(prompts))] == gp["seq_kv_lens"]
-    inter = [SimpleNamespace(request_id=rids[i], is_prompt=True, block_tables={i: list(bm.get_block_table(i))},
-                             seq_kv_lens={i: bm.get_seq_kv_len(i)}, seq_ids=[i], input_tokens=[[0] * n],
-                             orig_seq_lens=[n], seq_lens=[n], query_lens=[n], context_lens=[0])
-             for i, n in enumerate(prompts)]
-    meta = builder(inter).build(list(prompts), list(prompts), -1, len(prompts))
-    assert meta.slot_mapping.cpu().tolist() == gp["slot_mapping"]
+    # ---- prefill steps (a request is admitted, and its blocks allocated, at its step)
     step_rows = trace["prefill_row_step"]
-    for li in range(layers):
-        if trace["plain_prompts"]:
-            q, k, v = gen.step_inputs(seed + li, sum(prompts), Hq, Hkv, D, dt)
-        else:
-            q, k, v = gen.prompt_inputs(seed + li, prompts, Hq, Hkv, D, dt)
-        out = impls[li].forward(q.cuda(), k.cuda(), v.cuda(), kv[li], meta)
-        assert _sha(kv[li]) == gp["cache_sha"][li], (name, "prefill cache", li)
-        if f"{name}_prefill_out{li}" in zp.files:
-            ref = from_bits(zp[f"{name}_prefill_out{li}"], code).float()
-            _close(out[::step_rows].cpu().float(), ref, 2e-2, f"{name} prefill layer {li}")
-    assert impls[0].get_rmv_block_idx() == {}
+    for gi, gp in enumerate(trace["prefills"]):
+        idxs = gp["requests"]
+        assert idxs == trace["groups"][gi]
+        lens = [prompts[i] for i in idxs]
+        for i in idxs:
+            sched.add_request(rids[i], i, prompts[i])
+        assert [list(bm.get_block_table(i)) for i in idxs] == gp["tables"]
+        assert [bm.get_seq_kv_len(i) for i in idxs] == gp["seq_kv_lens"]
+        inter = [SimpleNamespace(request_id=rids[i], is_prompt=True, block_tables={i: list(bm.get_block_table(i))},
+                                 seq_kv_lens={i: bm.get_seq_kv_len(i)}, seq_ids=[i], input_tokens=[[0] * prompts[i]],
+                                 orig_seq_lens=[prompts[i]], seq_lens=[prompts[i]], query_lens=[prompts[i]],
+                                 context_lens=[0])
+                 for i in idxs]
+        meta = builder(inter).build(list(lens), list(lens), -1, len(idxs))
+        assert meta.slot_mapping.cpu().tolist() == gp["slot_mapping"]
+        pre = f"{name}_prefill" if gi == 0 else f"{name}_prefill{gi}"
+        for li in range(layers):
+            if trace["plain_prompts"]:
+                q, k, v = gen.step_inputs(seed + li + 100 * gi, sum(lens), Hq, Hkv, D, dt)
+            else:
+                q, k, v = gen.prompt_inputs(seed + li + 100 * gi, lens, Hq, Hkv, D, dt)
+            out = impls[li].forward(q.cuda(), k.cuda(), v.cuda(), kv[li], meta)
+            assert _sha(kv[li]) == gp["cache_sha"][li], (name, "prefill cache", gi, li)
+            if f"{pre}_out{li}" in zp.files:
+                ref = from_bits(zp[f"{pre}_out{li}"], code).float()
+                _close(out[::step_rows].cpu().float(), ref, 2e-2, f"{name} prefill {gi} layer {li}")
+        assert impls[0].get_rmv_block_idx() == {}
 
     # ---- decode
-    logical = list(prompts)
+    logical = {i: prompts[i] for g in trace["groups"] for i in g}
+    active = [i for g in trace["groups"] for i in g]
+    finish = {int(k): v for k, v in trace["finish"].items()}
     evictions = 0
     for step, gs in enumerate(trace["steps"]):
-        tables, kv_lens = sched.schedule_decode(rids)
+        for i in [i for i in active if finish.get(i) == step]:
+            sched.finish_request(rids[i])
+            active.remove(i)
+        assert active == gs["requests"]
+        tables, kv_lens = sched.schedule_decode([rids[i] for i in active])
         inter, adj = [], []
-        for i in range(len(prompts)):
+        for i in active:
             logical[i] += 1
             kvl = adjust_seq_kv_len(cfg, logical[i], kv_lens[i], BS)
             adj.append(kvl)
@@ -125,12 +143,13 @@ def test_backend_reproduces_reference_forward(trace):
                                          seq_kv_lens={i: kvl}, seq_ids=[i], input_tokens=[[0]],
                                          orig_seq_lens=[logical[i]], seq_lens=[logical[i]], query_lens=[1],
                                          context_lens=[logical[i] - 1]))
-        assert logical == gs["seq_lens"] and adj == gs["seq_kv_lens"], (name, step)
-        assert [list(tables[i]) for i in range(len(prompts))] == gs["tables"], (name, step)
-        meta = builder(inter).build(list(logical), [1] * len(prompts), -1, len(prompts))
+        lens = [logical[i] for i in active]
+        assert lens == gs["seq_lens"] and adj == gs["seq_kv_lens"], (name, step)
+        assert [list(tables[i]) for i in active] == gs["tables"], (name, step)
+        meta = builder(inter).build(list(lens), [1] * len(active), -1, len(active))
         assert meta.slot_mapping.cpu().tolist() == gs["slot_mapping"], (name, step)
         for li in range(layers):
-            q, k, v = gen.step_inputs(seed + 1000 * (step + 1) + li, len(prompts), Hq, Hkv, D, dt)
+            q, k, v = gen.step_inputs(seed + 1000 * (step + 1) + li, len(active), Hq, Hkv, D, dt)
             out = impls[li].forward(q.cuda(), k.cuda(), v.cuda(), kv[li], meta)
             got = {str(i): [r, int(b)] for i, (r, b) in impls[li].get_rmv_block_idx().items()}
             assert got == gs["rmv_by_layer"][li], (name, step, li)
@@ -141,6 +160,6 @@ def test_backend_reproduces_reference_forward(trace):
                 _close(out.cpu().float(), ref, 4e-3, f"{name} step {step} layer {li}")
         rmv = impls[0].get_rmv_block_idx()
         evictions += len(rmv)
-        sched.commit(rmv)
+        sched.commit(rmv)        # by the reported request id, as the engine does
     assert evictions == sum(len(s["rmv"]) for s in trace["steps"])
     ops.device_diagnostics(reset=True)      # HEAD's table forms make the kernels clamp; not an error here

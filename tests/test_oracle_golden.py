@@ -629,7 +629,7 @@ def test_backend_traces_oracle_walk(oracle, trace):
     import random
     gen = _backend_gen()
     name, method, budget = trace["name"], trace["method"], trace["budget"]
-    tag = "_llama" if name.startswith("llama_") else "_full" if name.startswith("full_") else ""
+    tag = next(("_" + g for g in ("llama", "full", "staged") if name.startswith(g + "_")), "")
     zp = np.load(os.path.join(GOLDEN, f"backend_traces{tag}_prefill.npz"))
     zd = np.load(os.path.join(GOLDEN, f"backend_traces{tag}_decode.npz"))
     Hq, Hkv, D, layers, nb = trace["Hq"], trace["Hkv"], trace["D"], trace["layers"], trace["num_blocks"]
@@ -647,68 +647,102 @@ def test_backend_traces_oracle_walk(oracle, trace):
         both = torch.stack([kc[li].reshape(nb, -1), vc[li].reshape(nb, -1)])
         return hashlib.sha256(both.contiguous().view(torch.int16).numpy().tobytes()).hexdigest()
 
-    # ---- prefill
-    gp = trace["prefill"]
-    slots = torch.tensor(gp["slot_mapping"])
-    scores = [[None] * B for _ in range(layers)]
-    for li in range(layers):
-        if trace["plain_prompts"]:
-            q, k, v = gen.step_inputs(seed + li, sum(prompts), Hq, Hkv, D, dt)
-        else:
-            q, k, v = gen.prompt_inputs(seed + li, prompts, Hq, Hkv, D, dt)
-        q3, k3, v3 = q.view(-1, Hq, D), k.view(-1, Hkv, D), v.view(-1, Hkv, D)
-        pk, pv, off = [], [], 0
-        for n in prompts:
-            a, b = oracle.prompt_prune(k3[off:off + n], v3[off:off + n], method or "streamingLLM", budget, bs,
-                                       compat_q2=True)
-            pk.append(a)
-            pv.append(b)
-            off += n
-        kept = [t.shape[0] for t in pk]
-        assert kept == gp["seq_kv_lens"]
-        oracle.reshape_and_cache(torch.cat(pk), torch.cat(pv), kc[li], vc[li], slots)
-        assert cache_sha(li) == gp["cache_sha"][li], (name, li)
-        if f"{name}_prefill_out{li}" in zp.files and sum(prompts) <= 1024:
-            # (the scalar C attention over the 4 x 1024-token prompts of the large-geometry traces
-            # would take minutes: there the GPU test compares the prefill outputs)
-            if trace["disable_evict_prefill"]:
-                out = oracle.prefill_attention(q3.float(), k3.float(), v3.float(), prompts, prompts, scale)
+    class HeadManager:
+        """Batch index -> request as HEAD resolves it (block_l2norm_manager.py:16-62): requests in
+        first-seen order, every request absent from a step forgotten, a request (re)added after the
+        first step starts from a zero score per block of its table."""
+
+        def __init__(self):
+            self.scores = None           # request -> score list, in insertion order
+
+        def update(self, requests, table_lens):
+            if self.scores is None:
+                self.scores = {r: [0.0] for r in requests}           # [0.0 * len(table)] (:28)
+                return
+            for r, n in zip(requests, table_lens):
+                if r not in self.scores:
+                    self.scores[r] = [0.0] * n
+            for r in [r for r in self.scores if r not in requests]:
+                del self.scores[r]
+
+        def flat(self):
+            return list(self.scores)
+
+    mgrs = [HeadManager() for _ in range(layers)]
+    # ---- prefill steps
+    for gi, gp in enumerate(trace["prefills"]):
+        idxs = gp["requests"]
+        lens = [prompts[i] for i in idxs]
+        slots = torch.tensor(gp["slot_mapping"])
+        pre = f"{name}_prefill" if gi == 0 else f"{name}_prefill{gi}"
+        for li in range(layers):
+            mgrs[li].update(idxs, [len(t) for t in gp["tables"]])
+            if trace["plain_prompts"]:
+                q, k, v = gen.step_inputs(seed + li + 100 * gi, sum(lens), Hq, Hkv, D, dt)
             else:
-                out = oracle.prefill_attention(q3.float(), torch.cat(pk).float(), torch.cat(pv).float(), prompts,
-                                               kept, scale)
-            ref = from_bits(zp[f"{name}_prefill_out{li}"], code).float().view(-1, Hq, D)
-            _rel_close(out[::trace["prefill_row_step"]], ref, 2e-2, f"{name} prefill {li}")
-        for i in range(B):     # one score per full block of the pruned prompt (:1278-1288)
-            scores[li][i] = [oracle.block_score_formula(pk[i][b * bs:(b + 1) * bs].contiguous(),
-                                                        pv[i][b * bs:(b + 1) * bs].contiguous(),
-                                                        "value_l2").float().item() for b in range(kept[i] // bs)]
+                q, k, v = gen.prompt_inputs(seed + li + 100 * gi, lens, Hq, Hkv, D, dt)
+            q3, k3, v3 = q.view(-1, Hq, D), k.view(-1, Hkv, D), v.view(-1, Hkv, D)
+            pk, pv, off = [], [], 0
+            for n in lens:
+                a, b = oracle.prompt_prune(k3[off:off + n], v3[off:off + n], method or "streamingLLM", budget, bs,
+                                           compat_q2=True)
+                pk.append(a)
+                pv.append(b)
+                off += n
+            kept = [t.shape[0] for t in pk]
+            assert kept == gp["seq_kv_lens"]
+            oracle.reshape_and_cache(torch.cat(pk), torch.cat(pv), kc[li], vc[li], slots)
+            assert cache_sha(li) == gp["cache_sha"][li], (name, gi, li)
+            if f"{pre}_out{li}" in zp.files and sum(lens) <= 1024:
+                # (the scalar C attention over the 4 x 1024-token prompts of the large-geometry traces
+                # would take minutes: there the GPU test compares the prefill outputs)
+                if trace["disable_evict_prefill"] or method is None:
+                    out = oracle.prefill_attention(q3.float(), k3.float(), v3.float(), lens, lens, scale)
+                else:
+                    out = oracle.prefill_attention(q3.float(), torch.cat(pk).float(), torch.cat(pv).float(), lens,
+                                                   kept, scale)
+                ref = from_bits(zp[f"{pre}_out{li}"], code).float().view(-1, Hq, D)
+                _rel_close(out[::trace["prefill_row_step"]], ref, 2e-2, f"{name} prefill {gi} {li}")
+            if any(n > budget for n in lens):
+                # one score per full block of the pruned prompt, by index in the prefill batch
+                # (:1278-1288; the driver returns before this when no prompt exceeds the budget)
+                for j, r in enumerate(mgrs[li].flat()[:len(idxs)]):
+                    mgrs[li].scores[r] = [
+                        oracle.block_score_formula(pk[j][b * bs:(b + 1) * bs].contiguous(),
+                                                   pv[j][b * bs:(b + 1) * bs].contiguous(),
+                                                   "value_l2").float().item() for b in range(kept[j] // bs)]
     # ---- decode
     rng = random.Random(1234)            # the global stream every layer's impl draws from (:796)
     for step, gs in enumerate(trace["steps"]):
-        L, kv_adj, tables = gs["seq_lens"], gs["seq_kv_lens"], gs["tables"]
+        reqs, L, kv_adj, tables = gs["requests"], gs["seq_lens"], gs["seq_kv_lens"], gs["tables"]
+        B = len(reqs)
+        table_of = dict(zip(reqs, tables))
         M = max(len(t) for t in tables)
         bt = _padded(tables, M)
         trig = [oracle.decode_trigger(L[i], budget, bs) for i in range(B)]
         for li in range(layers):
+            mgrs[li].update(reqs, [len(t) for t in tables])
+            flat = mgrs[li].flat()                 # batch index i is resolved to request flat[i]
+            flat_tables = [table_of[r] for r in flat]
             q, k, v = gen.step_inputs(seed + 1000 * (step + 1) + li, B, Hq, Hkv, D, dt)
             zero, rmv = [], [-1] * B
             if method is None:
                 pass
             elif method in ("streamingLLM", "streamingLLM-1"):
-                rmv, zero = oracle.decode_streaming(L, tables, budget, bs, method)
+                rmv, zero = oracle.decode_streaming(L, flat_tables, budget, bs, method)
             elif method == "inverse_key_l2":
-                zero = oracle.decode_inverse_key_l2(L, tables, budget, bs, rng)
+                zero = oracle.decode_inverse_key_l2(L, flat_tables, budget, bs, rng)
             elif trace["random_evict"]:
                 for i in range(B):
                     if trig[i]:
-                        end = 1 + 3 if method == "local" else len(tables[i]) - 1
+                        end = 1 + 3 if method == "local" else len(flat_tables[i]) - 1
                         rmv[i] = rng.randint(1, end - 1)
             else:
                 for i in range(B):
                     if trig[i]:       # the decision precedes the step's KV write (:942-947)
-                        new = oracle.block_score(vc[li][tables[i][-1]], bs, Hkv, D, 2)
-                        rmv[i] = oracle.decode_topk_victim(scores[li][i], new, method, 3, False)
-            expect = {str(i): [f"r{i}", r] for i, r in enumerate(rmv) if r >= 0}
+                        new = oracle.block_score(vc[li][flat_tables[i][-1]], bs, Hkv, D, 2)
+                        rmv[i] = oracle.decode_topk_victim(mgrs[li].scores[flat[i]], new, method, 3, False)
+            expect = {str(i): [f"r{flat[i]}", r] for i, r in enumerate(rmv) if r >= 0}
             assert expect == gs["rmv_by_layer"][li], (name, step, li)
             oracle.reshape_and_cache(k.view(B, Hkv, D), v.view(B, Hkv, D), kc[li], vc[li],
                                      torch.tensor(gs["slot_mapping"]))
