@@ -1,4 +1,4 @@
-"""Soak of tests/test_gpu_fuzz.py over further seeds: python tools/fuzz_soak.py <first seed> <end seed>
+"""Soak of tests/test_gpu_fuzz.py over further seeds: python tests/soak_fuzz.py <first seed> <end seed>
 (every method case x the three scheduler forms per seed; progress on stdout).  A run that only
 misses the test's own coverage floor (too few evictions for that seed) counts as passed."""
 import sys, os, time, traceback
