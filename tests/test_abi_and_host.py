@@ -109,6 +109,23 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "pe_oracle" not in src and "oracle/" not in src and "import oracle" not in src, f
+    # the measurement and tuning scripts time the product too: none of them may load the checker
+    # (tools/sanitize_oracle.sh builds the checker itself, for the CPU suite)
+    tools = os.path.join(ROOT, "tools")
+    for dirpath, dirs, files in os.walk(tools):
+        dirs[:] = [d for d in dirs if d != "_exp"]
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "pe_oracle" not in src and "import oracle" not in src, f
+    # bench.py: only inside cpu_baseline()
+    import ast
+    tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
+    for node in tree.body:
+        seg = ast.get_source_segment(open(os.path.join(ROOT, "bench.py")).read(), node) or ""
+        if "pe_oracle" in seg or "oracle" in seg.replace("the oracle", ""):
+            assert isinstance(node, ast.FunctionDef) and node.name == "cpu_baseline", \
+                f"bench.py touches the checker outside cpu_baseline(): {seg[:80]}"
 
 
 def test_paged_evict_config_validation():
