@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 BS = 16
 HQ, HKV, D, LAYERS = 8, 2, 64, 2
 BUDGET, TOPK = 128, 3
-FREQ, NBM = 2, 2   # percentage prune type ("pct:<decode method>" cases)
+FREQ = 2           # percentage prune type ("pct:<decode method>" cases; "pct3:" merges 3 blocks)
 
 
 def _rand(T, H, g, scale):
@@ -26,7 +26,8 @@ def _rand(T, H, g, scale):
 @pytest.mark.parametrize("method,seed,evict_before_prefill", [
     ("streamingLLM", 0, False), ("streamingLLM-1", 1, False), ("global", 2, False), ("global", 3, False),
     ("local", 4, False), ("streamingLLM", 5, True), ("global", 6, True),
-    ("pct:streamingLLM", 7, False), ("pct:value_l2", 8, False), ("pct:value_l2", 9, True)])
+    ("pct:streamingLLM", 7, False), ("pct:value_l2", 8, False), ("pct:value_l2", 9, True),
+    ("pct3:value_l2", 10, False), ("pct3:streamingLLM", 11, False)])
 def test_continuous_batching_fuzz(oracle, method, seed, evict_before_prefill, vectorised):
     from vllm_paged_compression_amd.backend import PagedEvictBackend
     from vllm_paged_compression_amd.batch_scheduler import BatchEvictionScheduler
@@ -36,9 +37,10 @@ def test_continuous_batching_fuzz(oracle, method, seed, evict_before_prefill, ve
     rng = random.Random(100 + seed)
     g = torch.Generator().manual_seed(200 + seed)
     nb = 160
-    pct = method.startswith("pct:")
+    pct = method.startswith("pct")
+    NBM = 3 if method.startswith("pct3:") else 2
     if pct:
-        method = method[4:]
+        method = method.split(":", 1)[1]
         cfg = PagedEvictConfig(not evict_before_prefill, "percentage", "streamingLLM", 0, -1,
                                evict_freq=FREQ, num_block_merge=NBM, decode_evict_method=method)
     else:
@@ -53,8 +55,6 @@ def test_continuous_batching_fuzz(oracle, method, seed, evict_before_prefill, ve
     vc_cpu = [torch.zeros(nb, HKV, D, BS, dtype=torch.bfloat16) for _ in range(LAYERS)]
     ref_sched = EvictionScheduler(EvictBlockSpaceManager(BS, nb, cfg, watermark=0.0))
     bm = ref_sched.block_manager
-    if vectorised == "device" and pct:
-        pytest.skip("the percentage prune type keeps its tables on the host")
     # "device": the vectorised scheduler with the running batch's tables resident on the GPU
     vec_sched = BatchEvictionScheduler(BS, nb, cfg, max_seqs=8, max_blocks_per_seq=40,
                                        device="cuda:0" if vectorised == "device" else None) \

@@ -868,7 +868,8 @@ class PagedEvictImpl(_ImplBase):
             table_lens = np.fromiter((len(table_of(i)) for i in range(n_seqs)), dtype=np.int64,
                                      count=n_seqs)
         if cfg.cache_prune_type == "percentage":
-            dec = self._decode_decision_percentage(dm, L, table_lens, req_ids)
+            dec = self._decode_decision_percentage(dm, L, table_lens, req_ids,
+                                                   getattr(batch, "device_state", None))
             if not self.compat.per_layer_decision:
                 step["decode"] = dec
             return dec
@@ -1061,11 +1062,13 @@ class PagedEvictImpl(_ImplBase):
         return dec
 
     def _decode_decision_percentage(self, dm, L: np.ndarray, table_lens: np.ndarray,
-                                    req_ids: List[str]) -> Dict[str, Any]:
+                                    req_ids: List[str], st=None) -> Dict[str, Any]:
         """Decode step of the percentage prune type (kvcache_prunner_old.py:264-295,
         page_evict_kv_util_bak.py:66-106, trigger torch_cuda_sdpa.py:1310): nothing depends on
         the data, so the decision is host arithmetic; the device compacts the tables and, for
-        value_l2, every layer merges its own blocks."""
+        value_l2, every layer merges its own blocks.  ``st``: the tables are device-resident
+        (``DeviceTableState``): the freed columns are closed inside the resident rows, the
+        merges read a copy of the columns they need taken before that."""
         cfg = self.paged_evict_config
         bs = self.cache_config.block_size
         ib, nbm = cfg.initial_blocks, cfg.num_block_merge
@@ -1081,13 +1084,28 @@ class PagedEvictImpl(_ImplBase):
         first_freed = ib + 1 if value_l2 else ib
         n_remove = nbm - 1
         M = dm.block_tables.shape[1]
-        width = min(max(int((table_lens - trig_np * n_remove).max()), 1), M)
         start = staging.upload_i32(np.where(trig_np, first_freed, -1), dev)
-        dec["tables"] = ops.block_table_remove_range(dm.block_tables, start, n_remove, width)
         dec["host_rmv"] = {int(i): (req_ids[i], first_freed) for i in np.nonzero(trig_np)[0]}
         if value_l2:
             dec["merge"] = staging.upload_i32(np.nonzero(trig_np)[0], dev)
             dec["merge_tables"] = dm.block_tables
+        if st is not None:
+            if self.compat.per_layer_decision:
+                raise NotImplementedError("device-resident block tables take one decision per step")
+            B = len(req_ids)
+            if value_l2:
+                # the merged group's block ids, before their columns close
+                dec["merge_tables"] = st.tables[:B, :ib + nbm].clone()
+            # a host-chosen victim column per triggered row, once per freed block (the next one
+            # has moved into the same column).  The launch applies it on block boundaries past its
+            # budget argument; a triggered row holds more than initial_blocks + num_block_merge
+            # >= 3 blocks, so the smallest budget the entry point takes lets every one through.
+            for _ in range(n_remove):
+                ops.evict_select_compact_inplace(st.tables, st.num_blocks, st.kv_lens, st.seq_lens, B,
+                                                 "global", 3 * bs, bs, victim_override=start)
+            return dec
+        width = min(max(int((table_lens - trig_np * n_remove).max()), 1), M)
+        dec["tables"] = ops.block_table_remove_range(dm.block_tables, start, n_remove, width)
         return dec
 
 

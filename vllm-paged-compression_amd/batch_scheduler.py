@@ -108,11 +108,9 @@ class BatchEvictionScheduler:
         """``device``: keep the running batch's tables on that GPU (``DeviceTableState``): decode
         steps then upload one int per sequence instead of the table matrix.  The arrays below
         remain the host's record of who owns which block (free-list accounting, the blocks to
-        release when a request finishes); they are brought up to date by ``commit``.  The
-        percentage prune type keeps the host form."""
+        release when a request finishes); they are brought up to date by ``commit``."""
         self.device_state: Optional[DeviceTableState] = None
-        if device is not None and not (paged_evict_config is not None
-                                       and paged_evict_config.cache_prune_type == "percentage"):
+        if device is not None:
             self.device_state = DeviceTableState(max_seqs, max_blocks_per_seq, device)
         self.block_size = block_size
         self.paged_evict_config = paged_evict_config
@@ -233,10 +231,15 @@ class BatchEvictionScheduler:
         lens = self.n_blocks[rows]
         if st is not None:
             cfg = self.paged_evict_config
-            rule = 0
-            if cfg is not None and cfg.evict_method in ("streamingLLM", "streamingLLM-1", "global", "local"):
-                rule = 1
-            st.advance(new_blocks, rule, cfg.cache_budget if cfg is not None else 0, bs)
+            if cfg is not None and cfg.cache_prune_type == "percentage":
+                # num_block_merge-1 blocks leave every evict_freq blocks (percentage_decode_trigger)
+                st.advance(new_blocks, 2, 0, bs, cfg.evict_freq, cfg.num_block_merge, cfg.initial_blocks)
+            else:
+                rule = 0
+                if cfg is not None and cfg.evict_method in ("streamingLLM", "streamingLLM-1", "global",
+                                                            "local"):
+                    rule = 1
+                st.advance(new_blocks, rule, cfg.cache_budget if cfg is not None else 0, bs)
             return DecodeBatch(list(request_ids), self._batch_seq_ids, rows, None, lens.copy(),
                                self.num_cached[rows], self.num_full[rows], device_state=st,
                                host_tables=self.tables)
