@@ -356,8 +356,7 @@ class Workload:
         # decode: one vectorised scheduler step + one metadata build per step
         L = L0
         es = 2
-        use_graph = a.graph_decode and not a.host_tables and not self.allreduce and not self.percentage \
-            and a.rope == "off"
+        use_graph = a.graph_decode and not a.host_tables and not self.allreduce and a.rope == "off"
         graph, warmed = None, False
         for it in range(a.output_len):
             batch = sched.schedule_decode(rids)
@@ -373,8 +372,11 @@ class Workload:
                 + 2 * B * self.Hq * self.D * es
             # a step whose sequences all stay below their eviction trigger launches nothing but
             # the layers' attention, always on the same device buffers: it can be replayed
-            plain = self.cfg is None or (self.cfg.evict_method in ("streamingLLM", "global", "local")
-                                         and not budget_decode_trigger(self.cfg, L, bs))
+            if self.percentage:      # a prune can only fall on a multiple of evict_freq blocks
+                plain = L % (bs * self.cfg.evict_freq) != 0
+            else:
+                plain = self.cfg is None or (self.cfg.evict_method in ("streamingLLM", "global", "local")
+                                             and not budget_decode_trigger(self.cfg, L, bs))
             if self.cos_sin is not None:
                 self.pos_d.fill_(L - 1)      # position of the step's token
             if use_graph and plain and warmed:
@@ -716,7 +718,7 @@ def main():
             "oproj_allreduce": bool(wl.allreduce), "rope": a.rope,
             "reference_head_compat": bool(a.reference_head_compat),
             "graph_decode": bool(a.graph_decode and not a.host_tables and not wl.allreduce
-                                 and not wl.percentage and a.rope == "off"), **kv},
+                                 and a.rope == "off"), **kv},
     }
     if os.environ.get("PE_BENCH_KV_CHECKSUM"):
         # bit-level sum of every layer's KV cache after the last generation (A/B of launch modes)

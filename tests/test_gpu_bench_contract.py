@@ -81,7 +81,8 @@ def test_bench_presets_select_the_baseline_configs():
     assert "budget 3072 (25% eviction)" in d["config"]["workload"]
 
 
-@pytest.mark.parametrize("extra", [["--evict", "0"], [], ["--decode-evict-method", "streamingLLM"]])
+@pytest.mark.parametrize("extra", [["--evict", "0"], [], ["--decode-evict-method", "streamingLLM"],
+                                   ["--cache-prune-type", "percentage", "--evict-freq", "2"]])
 def test_bench_graph_decode_leaves_the_same_kv_cache(extra):
     """--graph-decode replays the attention launches of the decode steps that evict nothing from
     a HIP graph; the KV caches of all layers must end bit-identical to the eager run's, with the
