@@ -9,7 +9,8 @@ import pytest
 import test_gpu_fuzz as F
 fn = F.test_continuous_batching_fuzz
 cases = [("streamingLLM", False), ("streamingLLM-1", False), ("global", False), ("local", False),
-         ("streamingLLM", True), ("global", True), ("local", True), ("pct:streamingLLM", False), ("pct:value_l2", False), ("pct:value_l2", True)]
+         ("streamingLLM", True), ("global", True), ("local", True), ("pct:streamingLLM", False), ("pct:value_l2", False), ("pct:value_l2", True),
+         ("pct3:value_l2", False), ("pct3:streamingLLM", True)]
 t0 = time.time(); n = fails = 0
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
 for seed in range(lo, hi):

@@ -261,6 +261,44 @@ def test_random_victim_stream(oracle):
     assert got == exp
 
 
+@pytest.mark.parametrize("nbm", [2, 3, 4])
+def test_batch_scheduler_percentage_frees_blocks_in_the_engine_order(nbm):
+    """Percentage prune type: a prune frees num_block_merge-1 blocks of a request, and several
+    requests prune on the same step.  The blocks must return to the free list request by request
+    (llm_engine.py:1189-1193 commits one request after the other), or the block ids handed out
+    afterwards differ from the per-request scheduler's."""
+    from vllm_paged_compression_amd.batch_scheduler import BatchEvictionScheduler
+    from vllm_paged_compression_amd.block_table import EvictBlockSpaceManager, EvictionScheduler
+    from vllm_paged_compression_amd.config import PagedEvictConfig
+    from vllm_paged_compression_amd.page_evict_kv_util import percentage_decode_trigger
+    bs, nb, freq = 16, 200, 2
+    cfg = PagedEvictConfig(True, "percentage", "streamingLLM", 0, -1, evict_freq=freq, num_block_merge=nbm,
+                           decode_evict_method="value_l2")
+    ref = EvictionScheduler(EvictBlockSpaceManager(bs, nb, cfg, watermark=0.0))
+    vec = BatchEvictionScheduler(bs, nb, cfg, max_seqs=8, max_blocks_per_seq=40)
+    prompts = {"a": 200, "b": 200, "c": 232, "d": 140}      # a, b, c prune on the same steps
+    seq_of = {r: i for i, r in enumerate(prompts)}
+    for r, n in prompts.items():
+        ref.add_request(r, seq_of[r], n)
+        vec.add_request(r, seq_of[r], n)
+    running, logical, prunes = list(prompts), dict(prompts), 0
+    for step in range(100):
+        tables, kv_lens = ref.schedule_decode(running)
+        batch = vec.schedule_decode(running)
+        rmv = {}
+        for i, r in enumerate(running):
+            logical[r] += 1
+            assert batch.table_row(i) == list(tables[seq_of[r]]), (step, r)
+            assert int(batch.kv_lens[i]) == kv_lens[seq_of[r]]
+            if percentage_decode_trigger(cfg, logical[r], kv_lens[seq_of[r]], bs):
+                rmv[i] = (r, cfg.initial_blocks + 1)
+        prunes += len(rmv) > 1
+        ref.commit(rmv)
+        vec.commit(rmv)
+        assert vec.get_num_free_gpu_blocks() == ref.block_manager.get_num_free_gpu_blocks()
+    assert prunes >= 2
+
+
 def test_batch_scheduler_matches_per_request_scheduler():
     """The vectorised scheduler (struct of arrays, one numpy step per decode step) walks the same
     states as the per-request one: block tables, physical/logical lengths, free-block counts,

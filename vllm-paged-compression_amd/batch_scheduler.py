@@ -256,10 +256,13 @@ class BatchEvictionScheduler:
         cfg = self.paged_evict_config
         # percentage prune type: num_block_merge-1 consecutive blocks go, from the reported index
         n = cfg.num_block_merge - 1 if cfg is not None and cfg.cache_prune_type == "percentage" else 1
-        for _ in range(n):
-            self._free_column(reqids_to_rmv_block_idx)
+        freed = [self._free_column(reqids_to_rmv_block_idx) for _ in range(n)]
+        # back to the free list request by request (all of one request's blocks, then the next
+        # request's), the order in which the engine's loop frees them (llm_engine.py:1189-1193)
+        self._give(np.stack(freed, axis=1).reshape(-1))
 
-    def _free_column(self, reqids_to_rmv_block_idx: Dict[int, Tuple[str, int]]) -> None:
+    def _free_column(self, reqids_to_rmv_block_idx: Dict[int, Tuple[str, int]]) -> np.ndarray:
+        """Close the reported column of every listed request; returns the block ids it held."""
         bs = self.block_size
         items = list(reqids_to_rmv_block_idx.values())
         rows = np.fromiter((self._row_of_req[r] for r, _ in items), dtype=np.int64, count=len(items))
@@ -267,7 +270,7 @@ class BatchEvictionScheduler:
         n = self.n_blocks[rows].astype(np.int64)
         # tokens held by the victim: a full block unless it is the (possibly partial) last one
         fill = np.where(idx < n - 1, bs, self.num_cached[rows] - (n - 1) * bs)
-        self._give(self.tables[rows, idx].copy())
+        ids = self.tables[rows, idx].copy()
         m = int(n.max())
         cols = np.arange(m - 1, dtype=np.int64)[None, :]
         src = cols + (cols >= idx[:, None])
@@ -275,3 +278,4 @@ class BatchEvictionScheduler:
         self.tables[rows, n - 1] = 0  # keep the padding past a row's end zero
         self.n_blocks[rows] -= 1
         self.num_cached[rows] -= fill
+        return ids
