@@ -538,8 +538,8 @@ def test_prefill_reference_sdpa_forward_golden(ops):
 
 def test_prefill_tile_shapes_same_bits(ops):
     """pe_prefill_causal picks its tile shape from the declared maximum prompt length and the
-    number of 256-row tiles (16 rows x 8 waves up to 512 tokens, 32 x 8 from 2048 tokens with
-    >= 2048 tiles, 32 x 4 otherwise); max_q_len is an upper bound, so declaring a larger one
+    number of tiles (16 rows x 8 waves up to 512 tokens, 32 x 8 for long prompts, 16 x 4 for
+    launches of few tiles, 32 x 4 otherwise); max_q_len is an upper bound, so declaring a larger one
     moves the same data through each shape: the outputs must not differ in a single bit."""
     g = torch.Generator().manual_seed(12)
     Hq, Hkv, D = 32, 8, 128
@@ -551,6 +551,11 @@ def test_prefill_tile_shapes_same_bits(ops):
     cq, ck = _cu(q_lens).cuda(), _cu(kv_lens).cuda()
     outs = [ops.prefill_causal(q, k, v, cq, ck, m, D ** -0.5) for m in (512, 1024, 2048)]
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    # a launch with at most 256 tiles of 128 rows runs 64-row workgroups (16 rows x 4 waves): the
+    # first two requests on their own
+    n_q, n_kv = sum(q_lens[:2]), sum(kv_lens[:2])
+    few = ops.prefill_causal(q[:n_q], k[:n_kv], v[:n_kv], cq[:3], ck[:3], 512, D ** -0.5)
+    assert torch.equal(few, outs[0][:n_q])
 
 
 def test_prefill_matches_torch_sdpa_top_left(ops):

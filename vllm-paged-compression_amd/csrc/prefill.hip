@@ -448,11 +448,16 @@ extern "C" int pe_prefill_causal(void* out, const void* q, const void* k, const 
     // 8 KV heads x 128 unless noted, us per launch, 24 / 18 / 28): 32 x 256 tokens 53.8 / 49.4 / 69.3;
     // 16 x 512 70.4 / 68.0 / 83.8 (12 heads x 64: 20.9 / 19.5 / 21.4); 8 x 1024 100 / 104 / 117;
     // 8 x 1536 200 / 212 / 220; 8 x 2048 381 / - / 378; 8 x 4096 1243 / - / 1221; 8 x 8192 4238 / - / 4073;
-    // 1 x 32768 7572 / - / 7292; 8 x 4096 with 8 query heads on 1 KV head 320 / 351 / 326.  So:
-    // short prompts take the four-waves-per-SIMD shape (their workgroups are mostly start-up and
-    // diagonal tiles, which more resident waves hide better), long prompts with enough 256-row
-    // tiles to fill the chip several times over take the 256-row shape (half the K/V tile traffic
-    // per flop), everything else the 128-row default.  PE_PREFILL_SHAPE overrides (tuning runs).
+    // 1 x 32768 7572 / - / 7292; 8 x 4096 with 8 query heads on 1 KV head 320 / 351 / 326; one
+    // prompt alone, 24 / 14 / 28: 1 x 1024 26.3 / 25.0 / 33.9 (12 heads x 64: 19.7 / 12.6 / 24.9,
+    // 8 heads on 1 KV head: 24.2 / 21.2 / 31.7), 2 x 1024 32.2 / 36.6 / 37.2, 1 x 4096
+    // 177 / 224 / 167, 1 x 8192 581 / 780 / 568; 18 / 14: 1 x 512 15.6 / 13.2, 2 x 512 16.8 / 15.5.
+    // So: a launch with no more 128-row tiles than the chip has CUs takes 64-row workgroups (twice
+    // as many of them); other short prompts take the four-waves-per-SIMD shape (their workgroups
+    // are mostly start-up and diagonal tiles, which more resident waves hide better); long prompts take the
+    // 256-row shape (half the K/V tile traffic per flop) from 4096 tokens on with up to 4 query
+    // heads per KV head, or from 2048 with enough tiles to fill the chip several times over;
+    // everything else the 128-row default.  PE_PREFILL_SHAPE overrides (tuning runs).
     static const int shape_env = [] {
       const char* e = getenv("PE_PREFILL_SHAPE");
       return e ? atoi(e) : 0;
@@ -460,8 +465,11 @@ extern "C" int pe_prefill_causal(void* out, const void* q, const void* k, const 
     int shape = shape_env;
     if (shape == 0) {
       const int64_t tiles256 = (int64_t)num_seqs * num_heads * ((max_q_len + 255) / 256);
-      if (max_q_len <= 512) shape = 18;
-      else if (max_q_len >= 2048 && tiles256 >= 2048) shape = 28;
+      const int64_t tiles128 = (int64_t)num_seqs * num_heads * ((max_q_len + 127) / 128);
+      if (tiles128 <= 256) shape = 14;
+      else if (max_q_len <= 512) shape = 18;
+      else if ((max_q_len >= 4096 && num_heads / num_kv_heads <= 4) ||
+               (max_q_len >= 2048 && tiles256 >= 2048)) shape = 28;
       else shape = PF_DEFAULT_SHAPE;
     }
     const float sl2 = scale * 1.4426950408889634f;
