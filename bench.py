@@ -208,9 +208,10 @@ class Workload:
         if self.allreduce:
             from vllm_paged_compression_amd import parallel
             if parallel._one_shot.get(id(tp_group)) is None:
-                # decode-sized partials (<= 1 MiB) go through the one-shot exchange over the
-                # peer-mapped buffers, larger ones through the group's backend (RCCL)
-                parallel.enable_one_shot_all_reduce(tp_group, dev, 1 << 20)
+                # decode-sized partials (<= 8 MiB) go through the exchange over the peer-mapped
+                # buffers (one stage, or two from 256-512 KiB), larger ones through the group's
+                # backend (RCCL)
+                parallel.enable_one_shot_all_reduce(tp_group, dev, 8 << 20)
             self.o_partial_p = torch.zeros(Tp, self.hidden, dtype=self.dtype, device=dev)
             self.o_partial_d = torch.zeros(B, self.hidden, dtype=self.dtype, device=dev)
         self.cos_sin = None

@@ -518,6 +518,13 @@ int pe_rope_reshape_and_cache(void* query, void* key, const void* value, void* k
  *     order).  A rank whose peers do not show up within about two seconds stops waiting and
  *     counts a timeout (pe_ar_timeouts, a synchronising read) instead of hanging the GPU; its
  *     output is then undefined.
+ *   pe_allreduce_twostage: the same sum (same bits) as reduce-scatter + all-gather over the same
+ *     buffers - the reference's cross_device_reduce_2stage (csrc/custom_all_reduce.cuh:235-283),
+ *     which its dispatch takes from 512 KiB with up to 4 ranks and from 256 KiB with up to 8
+ *     (:476-483): rank r sums the r-th of `world` chunks, every rank collects the reduced chunks.
+ *     Arguments as pe_allreduce_oneshot; the reduced chunk lives behind the input in the slot, so
+ *     the message may take count*size + ceil(count*size / world) bytes of it at most.  The two
+ *     forms share the call sequence: seq counts the calls of both.
  * ---------------------------------------------------------------------------------- */
 int64_t pe_ar_buffer_bytes(int64_t max_message_bytes);
 int pe_ar_alloc(void** ptr_out, int64_t bytes);
@@ -530,6 +537,9 @@ int pe_ar_timeouts(const void* own_buffer, unsigned int* count_out);
 int pe_allreduce_oneshot(void* out, const void* in, int64_t count, int dtype,
                          void* const* peer_buffers, int rank, int world, int64_t buffer_bytes,
                          unsigned int seq, void* stream);
+int pe_allreduce_twostage(void* out, const void* in, int64_t count, int dtype,
+                          void* const* peer_buffers, int rank, int world, int64_t buffer_bytes,
+                          unsigned int seq, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Block copy / swap — backend-API obligations (vllm/attention/backends/abstract.py:79-94).

@@ -103,13 +103,90 @@ def test_one_shot_all_reduce_two_ranks_one_gpu():
     assert all(r[2] == 24 for r in res)
 
 
+def _worker_two_stage(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from vllm_paged_compression_amd import parallel
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        group = dist.group.WORLD
+        comm = parallel.enable_one_shot_all_reduce(group, dev, max_bytes=4 << 20)
+        g = torch.Generator().manual_seed(2000 + rank)
+        # with four ranks the reference's dispatch takes two stages from 512 KiB: decode-sized
+        # partials of a large batch, vector counts that do not divide by the ranks, and small
+        # messages below the threshold in between (both forms share the slots and the sequence)
+        cases = [(torch.bfloat16, (128, 8192), True), (torch.bfloat16, (8, 8192), False),
+                 (torch.bfloat16, (33, 8200), True), (torch.float32, (3, 50000), True),
+                 (torch.float16, (512, 4096), True), (torch.bfloat16, (64, 8192), True),
+                 (torch.bfloat16, (7, 4096), False)]
+        checked = 0
+        for rep in range(3):
+            comm.force_two_stage = rep == 2          # last round: tiny messages in two stages too
+            pending = []
+            for dtype, shape, two in cases + ([(torch.bfloat16, (8,), True), (torch.float32, (12,), True)]
+                                              if rep == 2 else []):
+                x_cpu = (torch.rand(shape, generator=g) * 2 - 1).to(dtype)
+                x = x_cpu.to(dev)
+                assert comm.should_use(x)
+                before = comm.calls_two_stage
+                parallel.all_reduce_sum(x, group)
+                assert comm.calls_two_stage - before == int(two or rep == 2)
+                pending.append((x_cpu, x))
+            for x_cpu, x in pending:
+                parts = [torch.empty_like(x_cpu) for _ in range(world)]
+                dist.all_gather(parts, x_cpu)
+                acc = torch.zeros(x_cpu.shape, dtype=torch.float32)
+                for p in parts:                              # rank order, f32 accumulation
+                    acc += p.float()
+                assert torch.equal(x.cpu(), acc.to(x_cpu.dtype)), (rank, x_cpu.dtype, tuple(x_cpu.shape), rep)
+                checked += 1
+        # what does not fit the slot with its reduced chunk is refused by the C entry point
+        from vllm_paged_compression_amd import _lib
+        lib = _lib.load()
+        big = torch.zeros(5 << 20, dtype=torch.uint8, device=dev).view(torch.bfloat16)
+        assert not comm.should_use(big)
+        rc = lib.pe_allreduce_twostage(big.data_ptr(), big.data_ptr(), big.numel(), _lib.PE_BF16, comm._ptrs,
+                                       rank, world, comm.buffer_bytes, 999, None)
+        assert rc == 4 and b"two-stage" in lib.pe_last_error()
+        assert comm.timeouts() == 0
+        parallel.disable_one_shot_all_reduce(group)
+        q.put((rank, "ok", checked))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, "fail", traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_stage_all_reduce_four_ranks_one_gpu():
+    """Reduce-scatter + all-gather over the same peer-mapped buffers (four processes sharing the
+    test GPU): bit for bit the rank-order f32 sum, chunk boundaries that do not divide evenly,
+    one-stage and two-stage calls interleaved without host synchronisation."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_two_stage, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=200) for _ in procs)
+    for p in procs:
+        p.join(30)
+    assert all(r[1] == "ok" for r in res), [r[2] for r in res if r[1] != "ok"]
+    assert all(r[2] == 23 for r in res)
+
+
 def test_one_shot_all_reduce_single_rank_is_identity():
     """world = 1 through the C ABI: out = in (the degenerate sum), no peers to wait for."""
     import ctypes
     from vllm_paged_compression_amd import _lib
     lib = _lib.load()
     nbytes = lib.pe_ar_buffer_bytes(1 << 16)
-    assert nbytes == 4096 + 2 * (1 << 16)
+    assert nbytes == 8192 + 2 * (1 << 16)
     buf = ctypes.c_void_p()
     _lib.check(lib.pe_ar_alloc(ctypes.byref(buf), nbytes), "ar_alloc")
     try:

@@ -88,6 +88,8 @@ SIGNATURES = {
     "pe_ar_timeouts": (c_int, [c_void_p, c_void_p]),
     "pe_allreduce_oneshot": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int, c_int,
                                      c_int64, ctypes.c_uint, c_void_p]),
+    "pe_allreduce_twostage": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int, c_int,
+                                     c_int64, ctypes.c_uint, c_void_p]),
     "pe_copy_blocks": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int,
                                c_void_p]),
     "pe_swap_blocks": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),

@@ -80,9 +80,10 @@ def broadcast_victims(rmv_idx: torch.Tensor, group: Optional[dist.ProcessGroup] 
 
 
 class OneShotAllReduce:
-    """One-shot all-reduce over peer-mapped buffers for decode-sized messages (the role of the
-    reference's CustomAllreduce, vllm/distributed/device_communicators/custom_all_reduce.py,
-    which ``GroupCoordinator`` tries before NCCL, vllm/distributed/parallel_state.py:357-379).
+    """All-reduce over peer-mapped buffers for decode-sized messages, in one stage or - for the
+    larger ones - two (the role of the reference's CustomAllreduce,
+    vllm/distributed/device_communicators/custom_all_reduce.py, which ``GroupCoordinator`` tries
+    before NCCL, vllm/distributed/parallel_state.py:357-379).
 
     Every rank allocates one shared buffer, exports it with HIP IPC, and maps its peers' buffers
     (the handles travel through ``dist.all_gather_object`` on ``group``, any backend).  Ranks
@@ -102,8 +103,16 @@ class OneShotAllReduce:
         if self.world > self.MAX_RANKS:
             raise ValueError(f"one-shot all-reduce serves up to {self.MAX_RANKS} ranks")
         self.max_bytes = int(max_bytes)
-        self.buffer_bytes = lib.pe_ar_buffer_bytes(self.max_bytes)
+        # the two-stage form keeps a rank's reduced chunk behind its input in the slot
+        self.two_stage_from = (None if self.world <= 2 else
+                               512 * 1024 if self.world <= 4 else 256 * 1024)
+        self.force_two_stage = False       # tests: every message through the two-stage form
+        slot = self.max_bytes
+        if self.world > 1:
+            slot += -(-self.max_bytes // (16 * self.world)) * 16
+        self.buffer_bytes = lib.pe_ar_buffer_bytes(slot)
         self.seq = 0
+        self.calls_two_stage = 0
         self._own = ctypes.c_void_p()
         self._peers = []
         with torch.cuda.device(self.device):
@@ -133,14 +142,24 @@ class OneShotAllReduce:
                 and n % 16 == 0 and x.data_ptr() % 16 == 0
                 and x.dtype in (torch.bfloat16, torch.float16, torch.float32))
 
+    def two_stage(self, nbytes: int) -> bool:
+        """The reference's choice between its two kernels (csrc/custom_all_reduce.cuh:476-483):
+        one stage for two ranks and for small messages, two stages (reduce-scatter + all-gather)
+        from 512 KiB with up to four ranks and from 256 KiB with up to eight."""
+        if self.force_two_stage:
+            return True
+        return self.two_stage_from is not None and nbytes >= self.two_stage_from
+
     def all_reduce(self, x: torch.Tensor) -> torch.Tensor:
         from . import _lib
         code = {torch.float32: _lib.PE_F32, torch.float16: _lib.PE_F16, torch.bfloat16: _lib.PE_BF16}[x.dtype]
         self.seq += 1
-        self._check(self._lib.pe_allreduce_oneshot(
-            x.data_ptr(), x.data_ptr(), x.numel(), code, self._ptrs, self.rank, self.world,
-            self.buffer_bytes, self.seq, torch.cuda.current_stream(self.device).cuda_stream),
-            "allreduce_oneshot")
+        two = self.two_stage(x.numel() * x.element_size())
+        fn = self._lib.pe_allreduce_twostage if two else self._lib.pe_allreduce_oneshot
+        self.calls_two_stage += int(two)
+        self._check(fn(x.data_ptr(), x.data_ptr(), x.numel(), code, self._ptrs, self.rank, self.world,
+                       self.buffer_bytes, self.seq, torch.cuda.current_stream(self.device).cuda_stream),
+                    "allreduce_twostage" if two else "allreduce_oneshot")
         return x
 
     def timeouts(self) -> int:
@@ -168,9 +187,10 @@ _one_shot = {}
 
 
 def enable_one_shot_all_reduce(group: Optional[dist.ProcessGroup], device,
-                               max_bytes: int = 1 << 20) -> OneShotAllReduce:
-    """Register a one-shot communicator for ``group``: ``all_reduce_sum`` then serves messages
-    of up to ``max_bytes`` through it and leaves larger ones to the group's backend (RCCL)."""
+                               max_bytes: int = 8 << 20) -> OneShotAllReduce:
+    """Register a peer-buffer communicator for ``group``: ``all_reduce_sum`` then serves messages
+    of up to ``max_bytes`` (default: the reference's max_size of 8 MiB,
+    custom_all_reduce.py:56) through it and leaves larger ones to the group's backend (RCCL)."""
     comm = OneShotAllReduce(group, device, max_bytes)
     _one_shot[id(group) if group is not None else None] = comm
     return comm
