@@ -79,6 +79,9 @@ def test_bench_presets_select_the_baseline_configs():
             "--output-len", "20", "--layers", "2")
     assert "Hq 64, Hkv 8" in d["config"]["workload"] and "TP=8" in d["config"]["workload"]
     assert "budget 3072 (25% eviction)" in d["config"]["workload"]
+    d = run("--config", "c5", "--num-prompts", "1", "--prefill-batch", "1", "--output-len", "20", "--layers", "1")
+    assert "32768->20" in d["config"]["workload"] and "budget 16384 (50% eviction)" in d["config"]["workload"]
+    assert d["roofline_prefill"]["flops_per_launch"] > 2e12      # one 32768-token prompt in one launch
 
 
 @pytest.mark.parametrize("extra", [["--evict", "0"], [], ["--decode-evict-method", "streamingLLM"],
