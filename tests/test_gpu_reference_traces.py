@@ -46,14 +46,7 @@ def _close(got, ref, atol, what):
                                msg=lambda m: f"{what}: {m}")
 
 
-# staged_scored_local is HEAD with its hard-coded random victims switched off AND requests admitted
-# over two prefill steps: there the reference's manager forgets the first group's scores at the
-# second prefill step, restarts them from zeros and scores the just-filled block of ANOTHER
-# request's table (block_l2norm_manager.py:34-61, torch_cuda_sdpa.py:1520).  The backend keeps a
-# sequence's scores while it runs and scores its own block; that combination is held to the trace
-# by the oracle walk only (tests/test_oracle_golden.py::test_backend_traces_oracle_walk).
-TRACES = [t for t in json.load(open(os.path.join(GOLDEN, "backend_traces.json")))
-          if t["name"] != "staged_scored_local"]
+TRACES = json.load(open(os.path.join(GOLDEN, "backend_traces.json")))
 
 
 @pytest.mark.parametrize("trace", TRACES, ids=[t["name"] for t in TRACES])

@@ -751,6 +751,10 @@ class PagedEvictImpl(_ImplBase):
         bs = self.cache_config.block_size
         table = self._table(values.device)
         keys = self._step_keys(meta)
+        if self.compat.request_order_first_seen:
+            # HEAD's manager forgets every request absent from a step, and a prefill step holds
+            # the new prompts only (block_l2norm_manager.py:48-53)
+            table.retain_only(keys)
         H, D = values.shape[1], values.shape[2]
         if values.stride(2) != 1 or values.stride(1) != D:
             raise RuntimeError("prompt values must be dense [tokens, heads, head_size] rows")
@@ -876,6 +880,17 @@ class PagedEvictImpl(_ImplBase):
         if self._score_table is not None:
             # a decode step lists every running sequence: whoever is absent has finished
             self._score_table.retain_only(keys)
+        if self.compat.request_order_first_seen and self._needs_scores():
+            # HEAD: a request its manager does not know (new, or forgotten at a prefill step it
+            # was absent from) is listed with one zero score per block of its table, at the step
+            # it appears (block_l2norm_manager.py:39-44)
+            table = self._table(dev)
+            known = set(table._row)
+            fresh = [i for i, k in enumerate(keys) if k not in known]
+            if fresh:
+                rows_f = [table.row_of(keys[i]) for i in fresh]
+                table.scores[staging.upload([np.asarray(rows_f, dtype=np.int64)], dev)[0]] = 0.0
+                table.set_counts(rows_f, [int(table_lens[i]) for i in fresh])
         st = getattr(batch, "device_state", None) if batch is not None else None
         if st is not None and not (self.compat.per_layer_decision or self.compat.block_table_slice_in_loop
                                    or self.compat.streaming_decode_original_table
@@ -957,7 +972,17 @@ class PagedEvictImpl(_ImplBase):
                 rows = staging.upload_i32([table.row_of(k) for k in keys], dev)
                 table.flush_new_rows()
                 new_scores = None
-                if self._tp_exact_scores() or self._score_formula() != "value_l2":
+                if self.compat.request_order_first_seen:
+                    # HEAD scores the last block of the table of the request batch row i is
+                    # RESOLVED to (torch_cuda_sdpa.py:1501,1520), which is another request's once
+                    # the manager's order has left the batch order
+                    last = staging.upload_i32([table_of(i)[-1] for i in range(n_seqs)], dev)
+                    flat = self.compat.score_flat_cache_view
+                    new_scores = self._formula_block_scores(
+                        key_cache, value_cache, last, n_seqs,
+                        ops.SCORE_CACHE_FLAT if flat else ops.SCORE_KEY_CACHE,
+                        ops.SCORE_CACHE_FLAT if flat else ops.SCORE_CACHE, value_cache.stride(0))
+                elif self._tp_exact_scores() or self._score_formula() != "value_l2":
                     # score of each sequence's just-filled block outside the decision launch: over
                     # ALL KV heads under tensor parallelism (local token sums -> all-reduce ->
                     # finish; identical on every rank, so no broadcast), or with key norms
