@@ -39,7 +39,7 @@ def decode_case(seed):
     Hkv = rng.choice([1, 2, 4, 8])
     Hq = Hkv * rng.choice([1, 2, 4, 8, 16])
     dtype = rng.choice([torch.bfloat16, torch.float16])
-    bs = 16
+    bs = rng.choice([16, 16, 8, 32])      # the reference's page sizes (scripts/diff_page_sizes.sh:16)
     S = rng.randint(1, 12)
     hi = rng.choice([80, 600, 2100])
     lens = [pick_len(rng, hi) for _ in range(S)]
@@ -72,7 +72,7 @@ def decode_case(seed):
                            None if slopes is None else slopes.cuda(), "auto", 1.0, 1.0)
     torch.testing.assert_close(out.cpu().float(), ref.float(), atol=ATOL[dtype], rtol=RTOL[dtype])
     # the same step with the last token's K/V arriving as rows: fused launch vs write + attention
-    if D in (64, 128, 256) and Hq // Hkv <= 16:      # shapes of the one-launch (MFMA) path
+    if (D in (64, 128) or (D == 256 and bs == 16)) and Hq // Hkv <= 16:   # the one-launch (MFMA) path
         k_new = ((torch.rand(S, Hkv, D, generator=g) * 2 - 1) * sc).to(dtype).cuda()
         v_new = ((torch.rand(S, Hkv, D, generator=g) * 2 - 1) * sc).to(dtype).cuda()
         slots = torch.tensor([int(bt[i, (n - 1) // bs]) * bs + (n - 1) % bs for i, n in enumerate(lens)],
@@ -89,7 +89,7 @@ def decode_case(seed):
         assert torch.equal(kc1, kc2) and torch.equal(vc1, vc2), "fused KV write differs"
         torch.testing.assert_close(o2.float(), o1.float(), atol=ATOL[dtype], rtol=RTOL[dtype])
     os.environ.pop("PE_DECODE_SPLITS", None)
-    return f"decode Hq{Hq} Hkv{Hkv} D{D} {str(dtype)[6:]} S{S} max{max(lens)} splits{splits} alibi{slopes is not None}"
+    return f"decode Hq{Hq} Hkv{Hkv} D{D} bs{bs} {str(dtype)[6:]} S{S} max{max(lens)} splits{splits} alibi{slopes is not None}"
 
 
 def prefill_case(seed):

@@ -56,11 +56,14 @@ def test_argument_checks_without_gpu():
         _lib.check(rc, "evict_select_compact")
     assert lib.pe_reshape_and_cache(None, None, None, None, None, 0, 0, 0, None, 0, None, 0, 8, 128, 16,
                                     4, 2, None) == 1
-    # a fused decode step the MFMA kernel cannot serve (block size 8) must be refused, not run as
-    # attention-only with the step's token left unwritten; nothing is dereferenced before that
+    # a fused decode step the MFMA kernel cannot serve (block size 4; 8, 16 and 32 are served) must
+    # be refused, not run as attention-only with the step's token left unwritten; nothing is
+    # dereferenced before that
     p = 1 << 20
-    assert lib.pe_paged_decode_supports_fused_write(32, 8, 128, 8, 2) == 0
-    rc = lib.pe_decode_step(p, p, p, p, p, p, p, p, p, None, 1, 32, 8, 128, 8, 4, 4, 4096, 1024, 1024,
+    assert lib.pe_paged_decode_supports_fused_write(32, 8, 128, 4, 2) == 0
+    assert [lib.pe_paged_decode_supports_fused_write(32, 8, 128, b, 2) for b in (8, 16, 32)] == [1, 1, 1]
+    assert lib.pe_paged_decode_supports_fused_write(32, 8, 256, 32, 2) == 0
+    rc = lib.pe_decode_step(p, p, p, p, p, p, p, p, p, None, 1, 32, 8, 128, 4, 4, 4, 4096, 1024, 1024,
                             8192, 1024, 0.1, 32, 2, None, 0, None)
     assert rc == 2 and b"fused KV write" in lib.pe_last_error()
     # the rotating decode step refuses, before touching the device, what its fragment layout
@@ -74,7 +77,8 @@ def test_argument_checks_without_gpu():
                                        0, None)
     assert step_rope(128, 16, 48, 1) == 2 and b"rot_dim 48" in lib.pe_last_error()
     assert step_rope(256, 16, 128, 1) == 2 and b"head_size 256" in lib.pe_last_error()
-    assert step_rope(128, 8, 128, 1) == 2 and b"MFMA decode path" in lib.pe_last_error()
+    assert step_rope(128, 4, 128, 1) == 2 and b"MFMA decode path" in lib.pe_last_error()
+    assert step_rope(128, 8, 128, 1) == 2 and b"16-token blocks" in lib.pe_last_error()
     # (positions may be NULL - the per-step table form - so the missing pointer here is the table;
     # a NULL positions with a table of fewer rows than sequences is refused as well)
     assert lib.pe_decode_step_rope(p, p, p, p, p, p, p, p, p, None, p, None, 128, 1, 4096, 1, 32, 8, 128,

@@ -161,8 +161,12 @@ DECODE_CASES = [
     (64, 8, 128, 16, torch.bfloat16, [200, 40]),
     (16, 1, 256, 16, torch.bfloat16, [130, 33]),
     (40, 40, 80, 16, torch.bfloat16, [77, 300]),      # generic path (head size)
-    (32, 8, 128, 32, torch.bfloat16, [100, 515]),     # generic path (block size)
-    (8, 2, 64, 8, torch.float16, [9, 130]),           # generic path (block size)
+    (32, 8, 128, 32, torch.bfloat16, [100, 515]),     # 32-token blocks
+    (8, 2, 64, 8, torch.float16, [9, 130]),           # 8-token blocks
+    (32, 8, 128, 8, torch.bfloat16, [1, 7, 8, 9, 15, 16, 17, 31, 32, 33, 300, 777]),
+    (32, 8, 64, 32, torch.float16, [1, 31, 32, 33, 63, 64, 65, 1000]),
+    (8, 1, 128, 32, torch.bfloat16, [3072, 100, 3088]),
+    (16, 1, 256, 32, torch.bfloat16, [130, 33]),      # generic path (head size 256 with 32-token blocks)
     (8, 2, 128, 16, torch.float32, [50, 333]),        # generic path (f32)
     (34, 2, 128, 16, torch.bfloat16, [70, 200]),      # 17 query heads per KV head -> generic
     # the remaining head sizes of the reference's sweep (tests/kernels/test_attention.py:30)
@@ -710,13 +714,16 @@ def disjoint_tables(lens, bs, nb, g):
 @pytest.mark.parametrize("Hq,Hkv,D,dtype", [(32, 8, 128, torch.bfloat16), (12, 12, 64, torch.float16),
                                             (8, 1, 128, torch.bfloat16)])
 @pytest.mark.parametrize("splits", [0, 3])
-def test_decode_step_fused_write(ops, oracle, Hq, Hkv, D, dtype, splits, monkeypatch):
+@pytest.mark.parametrize("bs", [16, 8, 32])
+def test_decode_step_fused_write(ops, oracle, Hq, Hkv, D, dtype, splits, bs, monkeypatch):
     """One launch (KV write + attention) == reshape_and_cache followed by paged attention:
-    cache bytes identical, outputs within the kernel tolerance."""
+    cache bytes identical, outputs within the kernel tolerance.  Block sizes 8, 16 and 32 (the
+    page sizes of the reference's scripts/diff_page_sizes.sh) all run the MFMA kernel."""
     if splits:
         monkeypatch.setenv("PE_DECODE_SPLITS", str(splits))
     g = torch.Generator().manual_seed(Hq + D)
-    bs, nb = 16, 400
+    nb = 6400 // bs
+    assert ops._lib.load().pe_paged_decode_supports_fused_write(Hq, Hkv, D, bs, 1 if dtype == torch.float16 else 2)
     lens = [1, 16, 17, 32, 33, 700, 784, 2000]       # kv length including the new token
     S = len(lens)
     sc = D ** -0.5

@@ -1,6 +1,6 @@
 // Single-query ("decode") attention over a paged KV cache on gfx950.
 //
-// Fast path (16-bit types, block_size 16, head_size in {64,128,256}, up to 16 query
+// Fast path (16-bit types, block_size 16 [8 and 32 with head sizes 64/128], head_size in {64,128,256}, up to 16 query
 // heads per KV head): one workgroup per (KV split, KV head, sequence); all query heads
 // that share the KV head are processed together, so every K and V byte is read from
 // HBM once.  K and V go straight from global memory into MFMA operand registers —
@@ -81,7 +81,14 @@ __host__ __device__ inline int64_t ws_stride(int head_size) { return head_size +
 // (NeoX: element d and d + rot_dim/2 sit in k-steps ks and ks + rot_dim/64 of the same lane when
 // rot_dim is a multiple of 64; GPT-J: adjacent elements), so Q is rotated in registers right after
 // it is loaded and the new K row before it is used and stored; neither tensor is written back.
-template <typename T, int HEAD_SIZE, int WAVES, bool ROPE>
+//
+// BLK: tokens per cache block (8, 16 or 32; the reference's page-size study runs all three,
+// scripts/diff_page_sizes.sh:16).  A tile is always 32 tokens - two 16-token halves, each one MFMA
+// row block: with 16-token blocks a half is one block and its K slab is the A-operand image as it
+// lies in memory; a 32-token block holds both halves (chunk rows of 512 bytes, a half is 256
+// contiguous bytes of each); with 8-token blocks a half spans two blocks and the lanes of a half
+// pick theirs (K: by token, V: by lane group).
+template <typename T, int HEAD_SIZE, int WAVES, bool ROPE, int BLK = 16>
 __global__ __launch_bounds__(WAVES * 64, (WAVES >= 16 ? 4 : (HEAD_SIZE <= 128 ? PE_DEC_OCC : 2)))
 void paged_decode_mfma_kernel(
     T* __restrict__ out, float* __restrict__ ws, const T* __restrict__ query,
@@ -101,7 +108,8 @@ void paged_decode_mfma_kernel(
   using vec4 = typename TR::vec4;
   constexpr int KS = HEAD_SIZE / 32;  // k-steps of S^T = K.Q^T
   constexpr int DT = HEAD_SIZE / 16;  // d-tiles of O^T
-  constexpr int BS = 16;
+  constexpr int BS = 16;              // tokens per tile half
+  static_assert(BLK == 8 || BLK == 16 || BLK == 32, "block size");
 
   const int split = blockIdx.x;
   const int kvh = blockIdx.y;
@@ -125,8 +133,8 @@ void paged_decode_mfma_kernel(
   // a length beyond what the table row can address is clamped (never read past the row) and
   // reported through the diagnostic word
   const int raw_len = seq_lens[seq];
-  const int seq_len = min(raw_len, max_num_blocks_per_seq * BS);
-  if (raw_len > max_num_blocks_per_seq * BS && threadIdx.x == 0 && split == 0 && kvh == 0)
+  const int seq_len = min(raw_len, max_num_blocks_per_seq * BLK);
+  if (raw_len > max_num_blocks_per_seq * BLK && threadIdx.x == 0 && split == 0 && kvh == 0)
     atomicOr(&decode_diag_word, (unsigned)PE_DIAG_DECODE_LEN_CLAMPED);
   // Fused KV write: the step's new token (position seq_len-1) is taken from new_key/new_value
   // directly and only the seq_len-1 older tokens are read from the cache, so the store of the
@@ -138,8 +146,8 @@ void paged_decode_mfma_kernel(
     has_new = new_slot >= 0 && new_slot < num_slots;
   }
   const int cached_len = has_new ? seq_len - 1 : seq_len;
-  const int n_blocks = (cached_len + BS - 1) / BS;
-  const int n_pairs = (n_blocks + 1) / 2;
+  const int n_blocks = (cached_len + BLK - 1) / BLK;
+  const int n_pairs = (cached_len + 2 * BS - 1) / (2 * BS);  // 32-token tiles
   const int pairs_per_split = (n_pairs + num_splits - 1) / num_splits;
   const int pair_begin = split * pairs_per_split;
   const int pair_end = min(n_pairs, pair_begin + pairs_per_split);
@@ -263,6 +271,50 @@ void paged_decode_mfma_kernel(
   const int v_lane_off = hc * BS + 4 * g;        // elements, + dt*16*BS
 
   auto issue = [&](DecTile<T, HEAD_SIZE>& t, int pair) {
+    if constexpr (BLK == 32) {
+      // one block holds the tile: half b = tokens 16b .. 16b+15 of every chunk row / value row
+      const int64_t pa = block_id(pair);
+      const T* kp = key_cache + pa * kv_block_stride + head_off + g * (BLK * 8) + hc * 8;
+      const T* vp = value_cache + pa * kv_block_stride + head_off + hc * BLK + 4 * g;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        t.k[0][ks] = __builtin_bit_cast(vec8, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kp + ks * (4 * BLK * 8))));
+        t.k[1][ks] = __builtin_bit_cast(vec8, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kp + ks * (4 * BLK * 8) + BS * 8)));
+      }
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        t.v[0][dt] = __builtin_bit_cast(vec4, __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(vp + dt * 16 * BLK)));
+        t.v[1][dt] = __builtin_bit_cast(vec4, __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(vp + dt * 16 * BLK + BS)));
+      }
+      return;
+    }
+    if constexpr (BLK == 8) {
+      // four blocks per tile (past the end: the last block again, masked); the K row of token hc
+      // of a half lies in the half's first block for hc < 8, the value tokens 4g .. 4g+3 in its
+      // first block for g < 2
+      const int last = n_blocks - 1;
+      const int64_t p0 = block_id(min(4 * pair, last));
+      const int64_t p1 = block_id(min(4 * pair + 1, last));
+      const int64_t p2 = block_id(min(4 * pair + 2, last));
+      const int64_t p3 = block_id(min(4 * pair + 3, last));
+      const int koff = g * (BLK * 8) + (hc & 7) * 8;
+      const int voff = hc * BLK + 4 * (g & 1);
+      const T* ka = key_cache + (hc < 8 ? p0 : p1) * kv_block_stride + head_off + koff;
+      const T* kb = key_cache + (hc < 8 ? p2 : p3) * kv_block_stride + head_off + koff;
+      const T* va = value_cache + (g < 2 ? p0 : p1) * kv_block_stride + head_off + voff;
+      const T* vb = value_cache + (g < 2 ? p2 : p3) * kv_block_stride + head_off + voff;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        t.k[0][ks] = __builtin_bit_cast(vec8, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ka + ks * (4 * BLK * 8))));
+        t.k[1][ks] = __builtin_bit_cast(vec8, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kb + ks * (4 * BLK * 8))));
+      }
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        t.v[0][dt] = __builtin_bit_cast(vec4, __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(va + dt * 16 * BLK)));
+        t.v[1][dt] = __builtin_bit_cast(vec4, __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(vb + dt * 16 * BLK)));
+      }
+      return;
+    }
     const int ia = 2 * pair;
     const int ib = min(2 * pair + 1, n_blocks - 1);  // odd tail: re-read A's neighbour, masked
     const int64_t pa = block_id(ia);
@@ -413,8 +465,8 @@ void paged_decode_mfma_kernel(
     }
     compute(tn, seq_len - 1, seq_len);
     // store the row into its cache slot (same bytes pe_reshape_and_cache writes)
-    const int64_t blk = new_slot / BS;
-    const int off = (int)(new_slot % BS);
+    const int64_t blk = new_slot / BLK;
+    const int off = (int)(new_slot % BLK);
     T* kdst = key_cache_w + blk * kv_block_stride + (int64_t)kvh * kv_head_stride;
     T* vdst = value_cache_w + blk * kv_block_stride + (int64_t)kvh * kv_head_stride;
     if constexpr (ROPE) {
@@ -422,15 +474,15 @@ void paged_decode_mfma_kernel(
       if (hc == 0) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
-          *reinterpret_cast<u32x4*>(kdst + ((4 * ks + g) * BS + off) * 8) =
+          *reinterpret_cast<u32x4*>(kdst + ((4 * ks + g) * BLK + off) * 8) =
               __builtin_bit_cast(u32x4, tn.k[0][ks]);
       }
     } else {
       for (int c = lane; c < HEAD_SIZE / 8; c += 64)
-        *reinterpret_cast<u32x4*>(kdst + (c * BS + off) * 8) =
+        *reinterpret_cast<u32x4*>(kdst + (c * BLK + off) * 8) =
             *reinterpret_cast<const u32x4*>(ksrc + c * 8);
     }
-    for (int d = lane; d < HEAD_SIZE; d += 64) vdst[d * BS + off] = vsrc[d];
+    for (int d = lane; d < HEAD_SIZE; d += 64) vdst[d * BLK + off] = vsrc[d];
   }
 
   // ---- merge the 4 lane groups' sums, then the waves through LDS -------------------
@@ -674,8 +726,11 @@ static bool mfma_path_ok(int num_heads, int num_kv_heads, int head_size, int blo
                          int64_t kv_head_stride) {
   if (env_int("PE_DECODE_FORCE_GENERIC", 0)) return false;
   if (dtype != PE_BF16 && dtype != PE_F16) return false;
-  if (block_size != 16) return false;
+  if (block_size != 16 && block_size != 8 && block_size != 32) return false;
   if (head_size != 64 && head_size != 128 && head_size != 256) return false;
+  // 8- and 32-token blocks (the page sizes of scripts/diff_page_sizes.sh:16) are built for the
+  // head sizes of the models that study runs (64, 128)
+  if (block_size != 16 && head_size == 256) return false;
   if (num_heads / num_kv_heads > 16) return false;
   if (q_stride % 8 || kv_block_stride % 8 || kv_head_stride % 8) return false;
   return true;
@@ -735,7 +790,8 @@ static int decode_impl(void* out, const void* query, const void* key_cache, cons
                    kv_block_stride, kv_head_stride)) {
     int splits = 1, waves = DEC_WAVES;
     choose_shape(num_seqs, num_heads, num_kv_heads, head_size, max_seq_len, &waves, &splits);
-    if (rope != nullptr && waves > 8) waves = 8;  // the rotating form is built for 4 and 8 waves
+    // the rotating form and the 8-/32-token-block forms are built for 4 and 8 waves
+    if ((rope != nullptr || block_size != 16) && waves > 8) waves = 8;
     float* ws = static_cast<float*>(workspace);
     if (splits > 1) {
       const int64_t need = (int64_t)splits * num_seqs * num_heads * ws_stride(head_size) * 4;
@@ -758,9 +814,37 @@ static int decode_impl(void* out, const void* query, const void* key_cache, cons
                      R ? rope->positions : nullptr, R ? (const T*)rope->cos_sin : nullptr,         \
                      R ? rope->rot_dim : 0, R ? rope->is_neox : 0, R ? rope->max_position : 0)
 #define PE_LAUNCH_DEC_W(T, HS, W) PE_LAUNCH_DEC_WR(T, HS, W, false)
+#define PE_LAUNCH_DEC_B(T, HS, W, B)                                                               \
+  if (lds > 64 * 1024)                                                                             \
+    (void)hipFuncSetAttribute(                                                                     \
+        reinterpret_cast<const void*>(&paged_decode_mfma_kernel<T, HS, W, false, B>),              \
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                     \
+  hipLaunchKernelGGL((paged_decode_mfma_kernel<T, HS, W, false, B>), grid, dim3(W * 64), lds, st,  \
+                     (T*)out, ws, (const T*)query, (const T*)key_cache, (const T*)value_cache,     \
+                     block_tables, seq_lens, alibi_slopes, num_heads, num_kv_heads,                \
+                     max_num_blocks_per_seq, q_stride, kv_block_stride, kv_head_stride, scale,     \
+                     splits, (const T*)new_key, (const T*)new_value, new_slots, new_k_stride,       \
+                     new_v_stride, num_slots, (T*)key_cache, (T*)value_cache, nullptr, nullptr, 0, \
+                     0, 0)
 #define PE_LAUNCH_DEC(T, HS)                               \
   do {                                                     \
-    if (rope != nullptr) {                                 \
+    if (block_size != 16) {                                \
+      if constexpr (HS <= 128) {                           \
+        if (block_size == 32) {                            \
+          if (waves == 8) {                                \
+            PE_LAUNCH_DEC_B(T, HS, 8, 32);                 \
+          } else {                                         \
+            PE_LAUNCH_DEC_B(T, HS, DEC_WAVES, 32);         \
+          }                                                \
+        } else {                                           \
+          if (waves == 8) {                                \
+            PE_LAUNCH_DEC_B(T, HS, 8, 8);                  \
+          } else {                                         \
+            PE_LAUNCH_DEC_B(T, HS, DEC_WAVES, 8);          \
+          }                                                \
+        }                                                  \
+      }                                                    \
+    } else if (rope != nullptr) {                          \
       if constexpr (HS <= 128) {                           \
         if (waves == 8) {                                  \
           PE_LAUNCH_DEC_WR(T, HS, 8, true);                \
@@ -782,6 +866,7 @@ static int decode_impl(void* out, const void* query, const void* key_cache, cons
       else PE_LAUNCH_DEC(T, 256);
     });
 #undef PE_LAUNCH_DEC
+#undef PE_LAUNCH_DEC_B
 #undef PE_LAUNCH_DEC_W
 #undef PE_LAUNCH_DEC_WR
     if (int rc = check_launch("paged_decode")) return rc;
@@ -804,8 +889,9 @@ static int decode_impl(void* out, const void* query, const void* key_cache, cons
   // generic path: attention only - it cannot take the step's token from registers, so a fused
   // call that lands here must fail instead of silently leaving the cache unwritten
   PE_REQUIRE(new_key == nullptr, PE_ERR_UNSUPPORTED,
-             "decode_step: fused KV write needs the MFMA path (16-bit dtype, block_size 16, "
-             "head_size 64/128/256, strides multiples of 8); ask "
+             "decode_step: fused KV write needs the MFMA path (16-bit dtype, block_size 16 with "
+             "head_size 64/128/256 or block_size 8/32 with head_size 64/128, strides multiples of "
+             "8); ask "
              "pe_paged_decode_supports_fused_write first");
   int gen_len = max_seq_len;
   if ((int64_t)max_num_blocks_per_seq * block_size < gen_len) gen_len = max_num_blocks_per_seq * block_size;
@@ -899,6 +985,9 @@ int pe_decode_step_rope(void* out, const void* query, const void* new_key, const
              PE_ERR_UNSUPPORTED,
              "decode_step_rope needs the MFMA decode path (16-bit dtype, block_size 16, head_size "
              "64/128, strides multiples of 8): use pe_rope_reshape_and_cache + pe_paged_decode");
+  PE_REQUIRE(block_size == 16, PE_ERR_UNSUPPORTED,
+             "decode_step_rope is built for 16-token blocks; use pe_rope_reshape_and_cache + "
+             "pe_paged_decode");
   PE_REQUIRE(head_size <= 128, PE_ERR_UNSUPPORTED,
              "decode_step_rope: head_size %d has no registers left for the rotation; use "
              "pe_rope_reshape_and_cache + pe_paged_decode", head_size);
