@@ -139,6 +139,11 @@ int pe_reshape_and_cache(const void* key, const void* value, void* key_cache,
  *   workspace      device scratch of at least pe_paged_decode_workspace_bytes(...) bytes;
  *                  may be NULL when that function returns 0
  * softmax follows the CUDA kernel: p = exp(l - max) / (sum + 1e-6) (:342).
+ * Kernel choice: 16-bit dtypes with block_size 16 (head_size 64/128/256) or block_size 8/32
+ * (head_size 64/128), up to 16 query heads per KV head and strides that are multiples of 8
+ * elements run the matrix-core kernel, which reads K/V once per KV head; everything else the
+ * reference's op accepts (other head sizes of paged_attn.py:37, f32, other block sizes) runs a
+ * general kernel with the same results and no tuning.
  * ---------------------------------------------------------------------------------- */
 int64_t pe_paged_decode_workspace_bytes(int num_seqs, int num_heads, int num_kv_heads,
                                         int head_size, int block_size, int max_seq_len);
