@@ -27,16 +27,22 @@ def _rand(T, H, g, scale):
     ("streamingLLM", 0, False), ("streamingLLM-1", 1, False), ("global", 2, False), ("global", 3, False),
     ("local", 4, False), ("streamingLLM", 5, True), ("global", 6, True),
     ("pct:streamingLLM", 7, False), ("pct:value_l2", 8, False), ("pct:value_l2", 9, True),
-    ("pct3:value_l2", 10, False), ("pct3:streamingLLM", 11, False)])
+    ("pct3:value_l2", 10, False), ("pct3:streamingLLM", 11, False),
+    # the other two page sizes of the reference's scripts/diff_page_sizes.sh
+    ("bs8:global", 12, False), ("bs32:global", 13, False), ("bs8:streamingLLM-1", 14, False),
+    ("bs32:streamingLLM", 15, True), ("bs32:local", 16, False)])
 def test_continuous_batching_fuzz(oracle, method, seed, evict_before_prefill, vectorised):
     from vllm_paged_compression_amd.backend import PagedEvictBackend
     from vllm_paged_compression_amd.batch_scheduler import BatchEvictionScheduler
     from vllm_paged_compression_amd.block_table import EvictBlockSpaceManager, EvictionScheduler
     from vllm_paged_compression_amd.config import CacheConfigView, PagedEvictConfig
 
+    BS = 16
+    if method.startswith("bs"):
+        BS, method = int(method[2:method.index(":")]), method.split(":", 1)[1]
     rng = random.Random(100 + seed)
     g = torch.Generator().manual_seed(200 + seed)
-    nb = 160
+    nb = 160 * 16 // BS
     pct = method.startswith("pct")
     NBM = 3 if method.startswith("pct3:") else 2
     if pct:
@@ -56,7 +62,7 @@ def test_continuous_batching_fuzz(oracle, method, seed, evict_before_prefill, ve
     ref_sched = EvictionScheduler(EvictBlockSpaceManager(BS, nb, cfg, watermark=0.0))
     bm = ref_sched.block_manager
     # "device": the vectorised scheduler with the running batch's tables resident on the GPU
-    vec_sched = BatchEvictionScheduler(BS, nb, cfg, max_seqs=8, max_blocks_per_seq=40,
+    vec_sched = BatchEvictionScheduler(BS, nb, cfg, max_seqs=8, max_blocks_per_seq=40 * max(1, 16 // BS),
                                        device="cuda:0" if vectorised == "device" else None) \
         if vectorised else None
 
