@@ -166,6 +166,11 @@ DECODE_CASES = [
     (32, 8, 128, 8, torch.bfloat16, [1, 7, 8, 9, 15, 16, 17, 31, 32, 33, 300, 777]),
     (32, 8, 64, 32, torch.float16, [1, 31, 32, 33, 63, 64, 65, 1000]),
     (8, 1, 128, 32, torch.bfloat16, [3072, 100, 3088]),
+    # Llama-3.2-3B (24 query heads on 8 KV heads) and Llama-3.2-1B (head size 64), the other two
+    # models of the reference's scripts (scripts/latency_test.sh:8), at their three page sizes
+    (24, 8, 128, 16, torch.bfloat16, [777, 784, 15]), (24, 8, 128, 8, torch.bfloat16, [777, 9]),
+    (24, 8, 128, 32, torch.bfloat16, [777, 33]), (32, 8, 64, 16, torch.bfloat16, [1040, 17]),
+    (32, 8, 64, 8, torch.bfloat16, [1040, 17]),
     (16, 1, 256, 32, torch.bfloat16, [130, 33]),      # generic path (head size 256 with 32-token blocks)
     (8, 2, 128, 16, torch.float32, [50, 333]),        # generic path (f32)
     (34, 2, 128, 16, torch.bfloat16, [70, 200]),      # 17 query heads per KV head -> generic
@@ -495,6 +500,8 @@ PREFILL_CASES = [
     (32, 8, 128, torch.bfloat16, [1024], [768]),
     (32, 8, 128, torch.bfloat16, [1, 17, 130, 300], [1, 17, 130, 300]),
     (8, 2, 128, torch.float16, [200, 77, 513], [96, 77, 260]),
+    (24, 8, 128, torch.bfloat16, [300, 130], [300, 96]),     # Llama-3.2-3B: 3 query heads per KV head
+    (32, 8, 64, torch.bfloat16, [513, 64], [513, 64]),       # Llama-3.2-1B
     (12, 12, 64, torch.float16, [333, 64], [333, 64]),
     (8, 8, 64, torch.bfloat16, [150], [100]),
     (4, 4, 80, torch.bfloat16, [70, 33], [48, 33]),     # generic path
