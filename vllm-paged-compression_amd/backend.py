@@ -426,6 +426,9 @@ class DeviceScoreTable:
         self.counts.index_copy_(0, idx, val)
         self._new = [r for r in self._new if r not in set(rows)]
 
+    def knows(self, key: Tuple[str, int]) -> bool:
+        return key in self._row
+
     def retain_only(self, live: List[Tuple[str, int]]) -> None:
         live_set = set(live)
         for key in [k for k in self._row if k not in live_set]:
@@ -885,8 +888,7 @@ class PagedEvictImpl(_ImplBase):
             # was absent from) is listed with one zero score per block of its table, at the step
             # it appears (block_l2norm_manager.py:39-44)
             table = self._table(dev)
-            known = set(table._row)
-            fresh = [i for i, k in enumerate(keys) if k not in known]
+            fresh = [i for i, k in enumerate(keys) if not table.knows(k)]
             if fresh:
                 rows_f = [table.row_of(keys[i]) for i in fresh]
                 table.scores[staging.upload([np.asarray(rows_f, dtype=np.int64)], dev)[0]] = 0.0
