@@ -176,6 +176,10 @@ class Workload:
         max_kv = (a.input_len + a.output_len) if self.cfg is None else kept + a.block_size + 1
         if self.percentage:
             max_kv = self.budget + a.output_len + a.block_size
+        elif self.cfg is not None and method == "inverse_key_l2":
+            # zeroes one slot per step past the budget and never frees a block
+            # (torch_cuda_sdpa.py:1435-1475, model_runner.py:545-547): the pruned prompt keeps growing
+            max_kv = kept + a.output_len + a.block_size
         self.blocks_per_seq = -(-max_kv // a.block_size) + 1
         self.blocks_per_seq_full = -(-(a.input_len + a.output_len) // a.block_size)
         self.num_blocks = B * self.blocks_per_seq + 8

@@ -264,6 +264,21 @@ int pe_prefill_causal(void* out, const void* q, const void* k, const void* v,
                       int64_t out_stride, float scale, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Zero rows for every layer at once.  The reference zeroes the evicted slots of streamingLLM-1 and
+ * inverse_key_l2 by appending zero rows to each layer's KV write (TmpCacheSingleton,
+ * vllm/worker/tmp_cache_singleton.py:8-88, torch_cuda_sdpa.py:919-933,962-976); the slots are the
+ * same for all layers of a step, so one launch at the start of the step zeroes them in every
+ * layer's cache and each layer keeps its one-launch decode step.
+ *   key_cache_ptrs / value_cache_ptrs  DEVICE arrays of num_layers device pointers (dense caches
+ *                                      of the layout above, all of one shape)
+ *   zero_slots                         device int64[num_zero_slots]; negative or out-of-range
+ *                                      entries are skipped
+ * ---------------------------------------------------------------------------------- */
+int pe_zero_slots_layers(void* const* key_cache_ptrs, void* const* value_cache_ptrs, int num_layers,
+                         const int64_t* zero_slots, int64_t num_zero_slots, int num_kv_heads,
+                         int head_size, int block_size, int64_t num_blocks, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Prompt prune, dense form.  Replaces KVCachePruner.prune_prompt_inplace
  * (vllm/attention/kvcache_prunner.py:167-281) driven per request by
  * _prune_prompts_keys_and_values_new (torch_cuda_sdpa.py:1222-1296): gathers the kept

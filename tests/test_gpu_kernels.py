@@ -753,6 +753,30 @@ def test_decode_step_fused_write(ops, oracle, Hq, Hkv, D, dtype, splits, bs, mon
     torch.testing.assert_close(out.cpu().float(), ref.float(), atol=ATOL[dtype], rtol=RTOL[dtype])
 
 
+@pytest.mark.parametrize("dtype,bs", [(torch.bfloat16, 16), (torch.float16, 8), (torch.bfloat16, 32)])
+def test_zero_slots_of_all_layers_in_one_launch(ops, dtype, bs):
+    """pe_zero_slots_layers leaves in every layer's cache exactly the bytes the per-layer zeroing of
+    pe_reshape_and_cache (zero_slots) leaves; padding (-1) and out-of-range slots are skipped."""
+    g = torch.Generator().manual_seed(31 + bs)
+    Hkv, D, nb, L = 4, 64, 12, 5
+    shape = (2, nb, bs * Hkv * D)
+    caches = [(torch.rand(shape, generator=g) - 0.5).to(dtype).cuda() for _ in range(L)]
+    want = [c.clone() for c in caches]
+    slots = torch.tensor([3, bs * 5 + 7, -1, bs * nb - 1, bs * nb + 4, bs + 1], dtype=torch.int64).cuda()
+    empty = torch.zeros(0, Hkv, D, dtype=dtype, device="cuda")
+    for c in want:
+        kc = c[0].view(nb, Hkv, D // 8, bs, 8)
+        vc = c[1].view(nb, Hkv, D, bs)
+        ops.reshape_and_cache(empty, empty, kc, vc, slots[:0], zero_slots=slots)
+    v_off = caches[0].stride(0) * caches[0].element_size()
+    kp = torch.tensor([c.data_ptr() for c in caches], dtype=torch.int64).cuda()
+    vp = torch.tensor([c.data_ptr() + v_off for c in caches], dtype=torch.int64).cuda()
+    ops.zero_slots_layers(kp, vp, slots, Hkv, D, bs, nb, dtype)
+    for a, b in zip(caches, want):
+        assert torch.equal(a, b)
+    assert int((caches[0] == 0).sum()) >= 4 * 2 * Hkv * D      # four valid slots, K and V rows
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("layout", [0, 1])
 def test_block_score_two_step_head_sharded(oracle, dtype, layout):

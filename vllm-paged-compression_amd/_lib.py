@@ -90,6 +90,8 @@ SIGNATURES = {
                                      c_int64, ctypes.c_uint, c_void_p]),
     "pe_allreduce_twostage": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int, c_int,
                                      c_int64, ctypes.c_uint, c_void_p]),
+    "pe_zero_slots_layers": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_int,
+                                     c_int64, c_int, c_void_p]),
     "pe_copy_blocks": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int,
                                c_void_p]),
     "pe_swap_blocks": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),

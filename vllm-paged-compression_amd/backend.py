@@ -389,6 +389,47 @@ class PagedEvictMetadataBuilder(_BuilderBase):
 
 
 # ------------------------------------------------------------------------------------------
+class _LayerCaches:
+    """The KV caches of the layers that share one cache configuration, as each layer's forward
+    last saw them, and their addresses as device arrays: lets the first layer of a decode step
+    zero the step's evicted slots in every layer's cache with one launch (the slots are the same
+    for all layers), so that each layer keeps its one-launch decode step."""
+
+    def __init__(self):
+        self.caches: Dict[int, torch.Tensor] = {}
+        self._built = None      # (key ptrs, value ptrs, set of cache addresses, shape, dtype)
+
+    def note(self, layer_idx: int, kv_cache: torch.Tensor) -> None:
+        old = self.caches.get(layer_idx)
+        if old is None or old.data_ptr() != kv_cache.data_ptr() or old.shape != kv_cache.shape:
+            self.caches[layer_idx] = kv_cache
+            self._built = None
+
+    def arrays(self, like: torch.Tensor):
+        """Pointer arrays over the registered caches that have ``like``'s shape, dtype and device."""
+        b = self._built
+        if b is None or b[3] != like.shape or b[4] != like.dtype or b[5] != like.device:
+            same = [c for _, c in sorted(self.caches.items())
+                    if c.shape == like.shape and c.dtype == like.dtype and c.device == like.device
+                    and c.is_contiguous()]
+            v_off = like.stride(0) * like.element_size()
+            kp = torch.tensor([c.data_ptr() for c in same], dtype=torch.int64).to(like.device)
+            vp = torch.tensor([c.data_ptr() + v_off for c in same], dtype=torch.int64).to(like.device)
+            b = self._built = (kp, vp, {c.data_ptr() for c in same}, like.shape, like.dtype, like.device)
+        return b[0], b[1], b[2]
+
+
+def _layer_caches_of(cache_config) -> Optional[_LayerCaches]:
+    """The registry lives on the cache configuration object the layers share (and dies with it)."""
+    reg = getattr(cache_config, "_pe_layer_caches", None)
+    if reg is None and cache_config is not None:
+        try:
+            reg = cache_config._pe_layer_caches = _LayerCaches()
+        except (AttributeError, TypeError):     # a configuration object that takes no attributes
+            return None
+    return reg
+
+
 class DeviceScoreTable:
     """Block scores of the running sequences, resident on the GPU: f32 [rows, width] plus a
     count per row; (request, sequence) pairs are mapped to rows on the host.  The device-side
@@ -552,6 +593,15 @@ class PagedEvictImpl(_ImplBase):
                 if dec.get("merge") is not None:
                     kc, vc = PagedAttention.split_kv_cache(kv_cache, self.num_kv_heads, self.head_size)
                     self.kv_cache_pruner.merge_blocks_in_cache(kc, vc, dec["merge_tables"], dec["merge"])
+            zeroed = attn_metadata._pe_step.get("zeroed")
+            if zeroed is not None:
+                self._note_cache(kv_cache)
+                if kv_cache.data_ptr() not in zeroed[0]:
+                    # this layer's cache was not known when the step's slots were zeroed
+                    kc, vc = PagedAttention.split_kv_cache(kv_cache, self.num_kv_heads, self.head_size)
+                    ops.reshape_and_cache(key[:0].view(0, self.num_kv_heads, self.head_size),
+                                          value[:0].view(0, self.num_kv_heads, self.head_size), kc, vc,
+                                          zeroed[1][:0], zero_slots=zeroed[1])
             o = torch.empty_like(query) if output is None else output
             launcher.run(query, key, value, kv_cache, o, rope)
             return o
@@ -577,6 +627,10 @@ class PagedEvictImpl(_ImplBase):
                 self.block_l2norm_mgr.update_reqs(attn_metadata.reqid_mapping_blocktables)
             attn_metadata._pe_step.setdefault("mgr", self.block_l2norm_mgr)
 
+        if self.enabled_paged_eviction and not is_profile_run \
+                and self.paged_evict_config.cache_prune_type == "budget" \
+                and self.paged_evict_config.evict_method in ("streamingLLM-1", "inverse_key_l2"):
+            self._note_cache(kv_cache)      # the methods that zero evicted slots (all layers at once)
         rope_dec = None
         if rope is not None:
             positions, cos_sin, is_neox = rope
@@ -803,6 +857,9 @@ class PagedEvictImpl(_ImplBase):
             if dec["tables"] is not None:
                 block_tables = dec["tables"]
             zero_slots = dec["zero_slots"]
+            if zero_slots is not None and kv_cache is not None and not self.compat.per_layer_decision:
+                zero_slots = self._zero_in_all_layers(meta, zero_slots, kv_cache, key_cache, value_cache,
+                                                      dm.slot_mapping)
             self._pending_rmv, self._pending_reqs = dec["rmv"], dec.get("req_ids")
             self._pending_readback = dec.get("readback")
             self.reqids_mapping_rmv_blockIdx = dec["host_rmv"] or {}
@@ -847,6 +904,32 @@ class PagedEvictImpl(_ImplBase):
         PagedAttention.forward_decode(q, key_cache, value_cache, block_tables, seq_lens_arg,
                                       max_len, self.kv_cache_dtype, self.num_kv_heads,
                                       self.scale, None, 1.0, 1.0, output=out[n0:])
+
+    def _note_cache(self, kv_cache: torch.Tensor) -> None:
+        if self.layer_idx >= 0 and kv_cache.numel() > 0:
+            reg = _layer_caches_of(self.cache_config)
+            if reg is not None:
+                reg.note(self.layer_idx, kv_cache)
+
+    def _zero_in_all_layers(self, meta, zero_slots, kv_cache, key_cache, value_cache, slot_mapping):
+        """The step's evicted slots (streamingLLM-1, inverse_key_l2: the same for every layer) are
+        zeroed in all known layers' caches by the first layer that gets here; returns what is left
+        for this layer to zero itself (None when its cache was covered)."""
+        step = meta._pe_step
+        self._note_cache(kv_cache)
+        zeroed = step.get("zeroed")
+        if zeroed is None:
+            reg = _layer_caches_of(self.cache_config)
+            if reg is None:
+                return zero_slots
+            kp, vp, covered = reg.arrays(kv_cache)
+            if not covered:
+                return zero_slots
+            nb = kv_cache.shape[1]
+            ops.zero_slots_layers(kp, vp, zero_slots, self.num_kv_heads, self.head_size,
+                                  self.cache_config.block_size, nb, kv_cache.dtype)
+            zeroed = step["zeroed"] = (covered, zero_slots)
+        return None if kv_cache.data_ptr() in zeroed[0] else zero_slots
 
     def _decode_decision(self, meta, dm, value_cache, key_cache=None) -> Dict[str, Any]:
         """Eviction decision of this decode step: taken by the first layer that runs and reused

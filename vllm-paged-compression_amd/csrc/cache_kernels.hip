@@ -137,6 +137,28 @@ __global__ void zero_slots_kernel(T* __restrict__ key_cache, T* __restrict__ val
   }
 }
 
+// the same for the caches of every layer in one launch: grid (slot, layer)
+template <typename T>
+__global__ void zero_slots_layers_kernel(void* const* __restrict__ key_ptrs,
+                                         void* const* __restrict__ value_ptrs,
+                                         const int64_t* __restrict__ zero_slots, int num_heads,
+                                         int head_size, int block_size, int64_t num_slots) {
+  constexpr int X = 16 / sizeof(T);
+  const int64_t slot = zero_slots[blockIdx.x];
+  if (slot < 0 || slot >= num_slots) return;
+  T* key_cache = static_cast<T*>(key_ptrs[blockIdx.y]);
+  T* value_cache = static_cast<T*>(value_ptrs[blockIdx.y]);
+  const int64_t blk = slot / block_size;
+  const int off = (int)(slot % block_size);
+  const int chunks = head_size / X;
+  for (int i = threadIdx.x; i < num_heads * head_size; i += blockDim.x) {
+    const int h = i / head_size, d = i % head_size;
+    key_cache[((blk * num_heads + h) * chunks + d / X) * (int64_t)block_size * X +
+              (int64_t)off * X + d % X] = (T)0.f;
+    value_cache[((blk * num_heads + h) * head_size + d) * (int64_t)block_size + off] = (T)0.f;
+  }
+}
+
 // out[i][h][:] = in[src(i,h)][h][:], 16 bytes per thread
 template <typename T>
 __global__ void prune_gather_kernel(const T* __restrict__ key, const T* __restrict__ value,
@@ -286,6 +308,27 @@ int pe_reshape_and_cache(const void* key, const void* value, void* key_cache, vo
     if (int rc = check_launch("zero_slots")) return rc;
   }
   return PE_OK;
+}
+
+int pe_zero_slots_layers(void* const* key_cache_ptrs, void* const* value_cache_ptrs, int num_layers,
+                         const int64_t* zero_slots, int64_t num_zero_slots, int num_kv_heads,
+                         int head_size, int block_size, int64_t num_blocks, int dtype, void* stream) {
+  using namespace pe;
+  PE_REQUIRE(num_layers >= 0 && num_zero_slots >= 0, PE_ERR_INVALID_ARG, "zero_slots_layers: negative count");
+  if (num_layers == 0 || num_zero_slots == 0) return PE_OK;
+  PE_REQUIRE(key_cache_ptrs && value_cache_ptrs && zero_slots, PE_ERR_INVALID_ARG,
+             "zero_slots_layers: null pointer");
+  PE_REQUIRE(num_kv_heads > 0 && head_size > 0 && block_size > 0 && num_blocks > 0 &&
+                 head_size % (16 / elem_size(dtype)) == 0,
+             PE_ERR_INVALID_ARG, "zero_slots_layers: bad sizes");
+  PE_REQUIRE(num_layers <= 65535, PE_ERR_UNSUPPORTED, "zero_slots_layers: grid too large");
+  PE_DISPATCH_ALL(dtype, T,
+                  hipLaunchKernelGGL(zero_slots_layers_kernel<T>,
+                                     dim3((unsigned)num_zero_slots, (unsigned)num_layers), dim3(256), 0,
+                                     static_cast<hipStream_t>(stream), key_cache_ptrs, value_cache_ptrs,
+                                     zero_slots, num_kv_heads, head_size, block_size,
+                                     num_blocks * block_size));
+  return check_launch("zero_slots_layers");
 }
 
 int pe_prompt_prune_gather(const void* key, const void* value, void* out_key, void* out_value,

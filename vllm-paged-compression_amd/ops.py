@@ -302,6 +302,21 @@ def copy_blocks(key_caches: List[torch.Tensor], value_caches: List[torch.Tensor]
                                   _stream(dev)), "copy_blocks")
 
 
+def zero_slots_layers(key_ptrs: torch.Tensor, value_ptrs: torch.Tensor, zero_slots: torch.Tensor,
+                      num_kv_heads: int, head_size: int, block_size: int, num_blocks: int,
+                      dtype: torch.dtype) -> None:
+    """Zero the K and V rows of ``zero_slots`` (int64) in the caches of all layers with one launch.
+    ``key_ptrs`` / ``value_ptrs``: device int64 tensors holding each layer's cache address."""
+    dev = _need_gpu(key_ptrs, value_ptrs, zero_slots)
+    if key_ptrs.dtype != torch.int64 or value_ptrs.dtype != torch.int64 or zero_slots.dtype != torch.int64 \
+            or key_ptrs.numel() != value_ptrs.numel():
+        raise RuntimeError("zero_slots_layers: int64 pointer arrays of equal length and int64 slots expected")
+    lib = _lib.load()
+    _lib.check(lib.pe_zero_slots_layers(_p(key_ptrs), _p(value_ptrs), key_ptrs.numel(), _p(zero_slots),
+                                        zero_slots.numel(), num_kv_heads, head_size, block_size,
+                                        num_blocks, _DT[dtype], _stream(dev)), "zero_slots_layers")
+
+
 def swap_blocks(src: torch.Tensor, dst: torch.Tensor, block_mapping: torch.Tensor) -> None:
     """block_mapping: CPU int64 [num_pairs, 2]; src/dst may live on the GPU or the host."""
     if block_mapping.device.type != "cpu":
