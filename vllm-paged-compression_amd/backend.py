@@ -396,13 +396,13 @@ class _LayerCaches:
     for all layers), so that each layer keeps its one-launch decode step."""
 
     def __init__(self):
-        self.caches: Dict[int, torch.Tensor] = {}
+        self.caches: Dict[str, torch.Tensor] = {}      # by layer name (unique per layer and model)
         self._built = None      # (key ptrs, value ptrs, set of cache addresses, shape, dtype)
 
-    def note(self, layer_idx: int, kv_cache: torch.Tensor) -> None:
-        old = self.caches.get(layer_idx)
+    def note(self, layer: str, kv_cache: torch.Tensor) -> None:
+        old = self.caches.get(layer)
         if old is None or old.data_ptr() != kv_cache.data_ptr() or old.shape != kv_cache.shape:
-            self.caches[layer_idx] = kv_cache
+            self.caches[layer] = kv_cache
             self._built = None
 
     def arrays(self, like: torch.Tensor):
@@ -906,10 +906,10 @@ class PagedEvictImpl(_ImplBase):
                                       self.scale, None, 1.0, 1.0, output=out[n0:])
 
     def _note_cache(self, kv_cache: torch.Tensor) -> None:
-        if self.layer_idx >= 0 and kv_cache.numel() > 0:
+        if self.prefix and kv_cache.numel() > 0:
             reg = _layer_caches_of(self.cache_config)
             if reg is not None:
-                reg.note(self.layer_idx, kv_cache)
+                reg.note(self.prefix, kv_cache)
 
     def _zero_in_all_layers(self, meta, zero_slots, kv_cache, key_cache, value_cache, slot_mapping):
         """The step's evicted slots (streamingLLM-1, inverse_key_l2: the same for every layer) are
