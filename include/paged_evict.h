@@ -74,6 +74,11 @@ typedef enum {
 
 const char* pe_last_error(void);
 int pe_version(void);
+/* Tunables read from the environment (PE_DECODE_SPLITS, PE_DECODE_WAVES, PE_DECODE_MERGE_LAUNCH,
+ * PE_EVICT_FAST, PE_PREFILL_SHAPE, ...: experiment and test switches, none is needed in
+ * production) are read once, on first use, so that no launch pays for getenv.  A process that
+ * changes one of them afterwards calls pe_reload_env() to have them read again. */
+void pe_reload_env(void);
 
 /* Conditions a kernel survives by clamping but that mean the caller passed inconsistent
  * arguments (the reference's kernels would read out of bounds instead).  The kernels record
@@ -87,10 +92,15 @@ enum {
   PE_DIAG_SCORE_ROW_FULL = 2,     /* pe_evict_select_compact: a sequence's score row already
                                      held score_table_width entries; the new block's score was
                                      not appended                                              */
-  PE_DIAG_TABLE_STATE_MISMATCH = 4 /* pe_table_state_advance: the step's token does not fall into
+  PE_DIAG_TABLE_STATE_MISMATCH = 4, /* pe_table_state_advance: the step's token does not fall into
                                      the last block of the device-resident row (host and device
                                      counters disagree, or the row is full); the token's slot
                                      was reported as -1 (not cached)                           */
+  PE_DIAG_DECODE_MERGE_TIMEOUT = 8 /* pe_paged_decode / pe_decode_step: the workgroup that merges
+                                     the KV splits of a (sequence, KV head) did not see a
+                                     sibling's partial result within two seconds (a workspace
+                                     shared by overlapping calls, or one that held stale ready
+                                     tags); its output rows were filled with NaN               */
 };
 int pe_device_diagnostics(unsigned int* flags_out, int reset);
 
@@ -137,7 +147,13 @@ int pe_reshape_and_cache(const void* key, const void* value, void* key_cache,
  *   alibi_slopes   optional device float[num_heads]
  *   max_seq_len    upper bound of seq_lens (sizes the split-KV partition count only)
  *   workspace      device scratch of at least pe_paged_decode_workspace_bytes(...) bytes;
- *                  may be NULL when that function returns 0
+ *                  may be NULL when that function returns 0.  It must be ZERO-FILLED before its
+ *                  first use with this library and written by nobody else between calls: the
+ *                  partial results of the KV splits are merged inside the attention launch (no
+ *                  second launch), each 64-bit word of a partial carrying a "ready" tag that the
+ *                  merging workgroup clears again once it has read the word, so a call leaves
+ *                  the workspace as tag-free as it found it.  Calls that overlap on one
+ *                  workspace (different streams) race on it.
  * softmax follows the CUDA kernel: p = exp(l - max) / (sum + 1e-6) (:342).
  * Kernel choice: 16-bit dtypes with block_size 16 (head_size 64/128/256) or block_size 8/32
  * (head_size 64/128), up to 16 query heads per KV head and strides that are multiples of 8
@@ -234,9 +250,14 @@ int pe_decode_step_rope(void* out, const void* query, const void* new_key, const
  * GPU the library runs on until the process ends.  The call allocates and frees nothing; a call
  * whose partials would not fit returns PE_ERR_WORKSPACE and launches nothing.  All calls on one
  * GPU share that GPU's array: calls that overlap on one GPU (different streams or threads) race
- * on it and must be serialised by the caller.  Every byte of the array that a call reads was
- * written by the same call, so nothing has to be cleared between calls.  Arguments and results
- * are those of pe_paged_decode. */
+ * on it and must be serialised by the caller.  The array starts zero-filled (static device
+ * storage) and every call clears the ready tags it set, so nothing has to be cleared between
+ * calls.  The array used is that of the device `stream` belongs to (of the current device for
+ * the NULL stream), which must be the current device.  pe_paged_decode_noalloc_max_bytes() also
+ * resolves the array's address on the current device: call it once per device at set-up, outside
+ * any stream capture, so that the first pe_paged_decode_noalloc on that device may run under
+ * capture (the address lookup loads the device image and is not a capturable operation).
+ * Arguments and results are those of pe_paged_decode. */
 int64_t pe_paged_decode_noalloc_max_bytes(void);
 int pe_paged_decode_noalloc(void* out, const void* query, const void* key_cache,
                             const void* value_cache, const int32_t* block_tables,
@@ -535,9 +556,21 @@ int pe_rope_reshape_and_cache(void* query, void* key, const void* value, void* k
  *     out may be in).  peer_buffers: HOST array of `world` device pointers, entry r = rank r's
  *     buffer as mapped in this process (own buffer at index `rank`).  seq: 1, 2, 3, ... - the
  *     number of this call, the same on every rank (all ranks issue the same calls in the same
- *     order).  A rank whose peers do not show up within about two seconds stops waiting and
- *     counts a timeout (pe_ar_timeouts, a synchronising read) instead of hanging the GPU; its
- *     output is then undefined.
+ *     order; it may wrap from 0xfffffffe to 1, never to an equal parity).  A workgroup whose
+ *     peers do not show up within timeout_us microseconds (<= 0: ten seconds) stops waiting
+ *     instead of hanging the GPU, stores NaN for its part of the output rather than a partial
+ *     sum, counts the event in the buffer header (pe_ar_timeouts, a synchronising read) and,
+ *     when status_host is given, sets status_host[0] != 0 ([1] = seq of the call, [2] = 1 + rank
+ *     of a missing peer).  The reference's barrier spins until the peer arrives
+ *     (csrc/custom_all_reduce.cuh:140-200) and so can hang but not return a partial sum.
+ *   pe_ar_status_alloc / pe_ar_status_free: 16 uint32 status words in pinned, device-mapped host
+ *     memory (set-up calls: they allocate).  The host reads them as plain memory before a call,
+ *     without touching the device; a communicator whose word 0 is set must not be used again.
+ *   pe_ar_selfcheck: verifies the peer mappings once at set-up.  phase 0 (all ranks, then a host
+ *     barrier with every device synchronised): each rank fills a pattern area of its own buffer
+ *     and writes tagged words into every rank's buffer through the mapping; phase 1: each rank
+ *     reads all peers' patterns through the mappings and the words its peers wrote into its own
+ *     buffer, and adds the number of mismatching threads to *mismatches_dev (device uint32).
  *   pe_allreduce_twostage: the same sum (same bits) as reduce-scatter + all-gather over the same
  *     buffers - the reference's cross_device_reduce_2stage (csrc/custom_all_reduce.cuh:235-283),
  *     which its dispatch takes from 512 KiB with up to 4 ranks and from 256 KiB with up to 8
@@ -554,12 +587,16 @@ int pe_ar_get_ipc_handle(void* ptr, void* handle_out);
 int pe_ar_open_ipc_handle(const void* handle, void** ptr_out);
 int pe_ar_close_ipc_handle(void* ptr);
 int pe_ar_timeouts(const void* own_buffer, unsigned int* count_out);
+int pe_ar_status_alloc(void** host_words_out);
+int pe_ar_status_free(void* host_words);
+int pe_ar_selfcheck(void* const* peer_buffers, int rank, int world, int phase,
+                    unsigned int* mismatches_dev, void* stream);
 int pe_allreduce_oneshot(void* out, const void* in, int64_t count, int dtype,
                          void* const* peer_buffers, int rank, int world, int64_t buffer_bytes,
-                         unsigned int seq, void* stream);
+                         unsigned int seq, void* status_host, int64_t timeout_us, void* stream);
 int pe_allreduce_twostage(void* out, const void* in, int64_t count, int dtype,
                           void* const* peer_buffers, int rank, int world, int64_t buffer_bytes,
-                          unsigned int seq, void* stream);
+                          unsigned int seq, void* status_host, int64_t timeout_us, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Block copy / swap — backend-API obligations (vllm/attention/backends/abstract.py:79-94).

@@ -40,3 +40,37 @@ def oracle():
     from oracle import pe_oracle
     pe_oracle.build()
     return pe_oracle
+
+
+def _reload_pe_env():
+    """The library reads its PE_* tunables once; tests that change one have it read them again."""
+    lib_mod = sys.modules.get("vllm_paged_compression_amd._lib")
+    if lib_mod is not None and getattr(lib_mod, "_lib", None) is not None:
+        lib_mod._lib.pe_reload_env()
+
+
+@pytest.fixture(autouse=True)
+def _pe_env_restored_after_test():
+    # set up before (so torn down after) monkeypatch: the library re-reads the restored environment
+    yield
+    _reload_pe_env()
+
+
+@pytest.fixture
+def monkeypatch(monkeypatch):
+    """The built-in fixture, with setenv / delenv of PE_* variables followed by a reload of the
+    library's cached tunables."""
+    set_env, del_env = monkeypatch.setenv, monkeypatch.delenv
+
+    def setenv(name, value, *a, **k):
+        set_env(name, value, *a, **k)
+        if name.startswith("PE_"):
+            _reload_pe_env()
+
+    def delenv(name, *a, **k):
+        del_env(name, *a, **k)
+        if name.startswith("PE_"):
+            _reload_pe_env()
+
+    monkeypatch.setenv, monkeypatch.delenv = setenv, delenv
+    return monkeypatch

@@ -65,6 +65,7 @@ def decode_case(seed):
         os.environ["PE_DECODE_SPLITS"] = str(splits)
     else:
         os.environ.pop("PE_DECODE_SPLITS", None)
+    ops.reload_env()
     ref = oracle.paged_attention(q, kc, vc, bt, lens_t, sc, slopes)
     out = torch.empty_like(q, device="cuda")
     kcg, vcg = kc.cuda(), vc.cuda()
@@ -89,6 +90,7 @@ def decode_case(seed):
         assert torch.equal(kc1, kc2) and torch.equal(vc1, vc2), "fused KV write differs"
         torch.testing.assert_close(o2.float(), o1.float(), atol=ATOL[dtype], rtol=RTOL[dtype])
     os.environ.pop("PE_DECODE_SPLITS", None)
+    ops.reload_env()
     return f"decode Hq{Hq} Hkv{Hkv} D{D} bs{bs} {str(dtype)[6:]} S{S} max{max(lens)} splits{splits} alibi{slopes is not None}"
 
 

@@ -28,9 +28,9 @@ def test_library_exports_every_declared_symbol():
     assert lib.pe_version() >= 101
     # workspace helpers are pure host functions
     # sized for the largest split count a launch may use: one split per 4 block pairs of 32 tokens,
-    # at most 64
-    assert lib.pe_paged_decode_workspace_bytes(64, 32, 8, 128, 16, 776) == 6 * 64 * 32 * (128 + 2) * 4
-    assert lib.pe_paged_decode_workspace_bytes(64, 32, 8, 128, 16, 100000) == 64 * 64 * 32 * (128 + 2) * 4
+    # at most 64; a partial is m, l and head_size outputs per head, one 64-bit word each (value + tag)
+    assert lib.pe_paged_decode_workspace_bytes(64, 32, 8, 128, 16, 776) == 6 * 64 * 32 * (128 + 2) * 8
+    assert lib.pe_paged_decode_workspace_bytes(64, 32, 8, 128, 16, 100000) == 64 * 64 * 32 * (128 + 2) * 8
     assert lib.pe_paged_decode_workspace_bytes(64, 32, 8, 128, 16, 220) == 0      # 7 pairs: one split
     prev = 0
     for n in range(1, 40000, 97):       # never shrinks as the maximum length grows
@@ -380,6 +380,45 @@ def test_batch_scheduler_matches_per_request_scheduler():
         ref.finish_request(r)
         vec.finish_request(r)
     assert vec.get_num_free_gpu_blocks() == nb == ref.block_manager.get_num_free_gpu_blocks()
+
+
+def test_batch_scheduler_reloads_device_rows_when_a_request_id_returns():
+    """A request that finishes and comes back under the same id (or a lone request preempted and
+    recomputed) gives the next decode batch the same id tuple as the resident rows: the device
+    rows must be rebuilt from the host record all the same, because the blocks and lengths
+    behind the id are new."""
+    import numpy as np
+    from vllm_paged_compression_amd.batch_scheduler import BatchEvictionScheduler
+
+    class RecordingState:
+        """Stands in for DeviceTableState (which needs a GPU): records what is loaded."""
+        def __init__(self):
+            self.key, self.score_rows_key, self.score_rows, self.loads = None, None, None, []
+
+        def load(self, key, tables, n_blocks, kv_lens, seq_lens):
+            self.loads.append((key, tables.copy(), n_blocks.copy(), kv_lens.copy(), seq_lens.copy()))
+            self.key = key
+
+        def advance(self, *a, **k):
+            pass
+
+    sched = BatchEvictionScheduler(16, 64, None, max_seqs=4, max_blocks_per_seq=16)
+    st = sched.device_state = RecordingState()
+    sched.add_request("r", 0, 40)
+    sched.schedule_decode(["r"])
+    sched.schedule_decode(["r"])
+    assert len(st.loads) == 1 and st.loads[0][3].tolist() == [40]
+    st.score_rows_key = st.key               # as the backend caches its score-row indices
+    sched.finish_request("r")
+    assert st.key is None and st.score_rows_key is None
+    sched.add_request("x", 1, 20)            # takes the blocks "r" gave back
+    sched.add_request("r", 2, 100)
+    sched.schedule_decode(["r"])             # same id tuple as the resident rows
+    assert len(st.loads) == 2
+    key, tables, n_blocks, kv_lens, seq_lens = st.loads[1]
+    assert key == ("r",) and kv_lens.tolist() == [100] and seq_lens.tolist() == [100]
+    assert tables[0, :n_blocks[0]].tolist() == sched.get_block_table("r")[:int(n_blocks[0])]
+    assert not set(tables[0, :n_blocks[0]].tolist()) & set(sched.get_block_table("x"))
 
 
 def test_launcher_signature_is_view_invariant():

@@ -175,3 +175,26 @@ def test_table_state_kernels_against_host_model(oracle):
     ops.table_state_advance(d_tab, bad_n, d_kv, d_L, t(np.full(B, -1)), B, slots, attn, None, 0, 0, BS)
     assert ops.device_diagnostics(reset=True) == ops.DIAG_TABLE_STATE_MISMATCH
     assert (slots == -1).all()
+
+
+def test_device_rows_follow_a_request_id_that_returns():
+    """finish_request + add_request of the same id between two decode steps: the resident rows are
+    rebuilt (the id tuple of the batch is unchanged, the blocks behind it are not)."""
+    from vllm_paged_compression_amd import ops
+    from vllm_paged_compression_amd.batch_scheduler import BatchEvictionScheduler
+    dev = torch.device("cuda:0")
+    sched = BatchEvictionScheduler(BS, 64, None, max_seqs=4, max_blocks_per_seq=16, device=dev)
+    sched.add_request("r", 0, 40)
+    sched.schedule_decode(["r"])
+    sched.finish_request("r")
+    sched.add_request("x", 1, 20)
+    sched.add_request("r", 2, 100)
+    batch = sched.schedule_decode(["r"])
+    st = sched.device_state
+    n = int(st.num_blocks[0])
+    assert st.loads == 2
+    assert st.tables[0, :n].cpu().tolist() == sched.get_block_table("r")
+    assert int(st.kv_lens[0]) == 101 == int(batch.kv_lens[0]) and int(st.seq_lens[0]) == 101
+    table = sched.get_block_table("r")
+    assert int(st.slot_mapping[0]) == table[100 // BS] * BS + 100 % BS
+    ops.check_device_diagnostics()

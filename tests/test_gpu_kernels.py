@@ -1044,7 +1044,7 @@ def test_decode_workspace_advertised_size_always_suffices(monkeypatch):
                     lens = torch.full((S,), kv, dtype=torch.int32).cuda()
                     out = torch.empty_like(q)
                     need = lib.pe_paged_decode_workspace_bytes(S, Hq, Hkv, D, 16, kv)
-                    ws = torch.empty(max(need, 1), dtype=torch.uint8, device="cuda")
+                    ws = torch.zeros(max(need, 1), dtype=torch.uint8, device="cuda")
                     rc = lib.pe_paged_decode(out.data_ptr(), q.data_ptr(), kc.data_ptr(), vc.data_ptr(),
                                              bt.data_ptr(), lens.data_ptr(), None, S, Hq, Hkv, D, 16, M,
                                              q.stride(0), kc.stride(0), kc.stride(1), D ** -0.5, kv,
@@ -1114,6 +1114,56 @@ def test_evict_select_kernels_agree(ops, method, topk, drop, inplace, monkeypatc
             if a is not None:
                 assert torch.equal(a, b), (method, B, M)
         assert (results[0][0] >= 0).any() or method == "streamingLLM-1"
+
+
+@pytest.mark.parametrize("inplace", [False, True])
+def test_evict_select_override_with_caller_scores(ops, inplace, monkeypatch):
+    """Caller-chosen victim + score table + caller-supplied new scores: the one combination in
+    which the fast kernel reaches the score-list shift without passing a barrier of the scoring or
+    arg-min branches.  Score rows of several hundred entries (the shift crosses wave boundaries),
+    both kernels must leave the same bits."""
+    g = torch.Generator().manual_seed(77)
+    bs, Hkv, D, nb = 16, 4, 64, 64
+    for B, M, budget in [(6, 300, 2048), (3, 1500, 8192)]:
+        nblk = torch.full((B,), budget // bs + 1, dtype=torch.int32)
+        nblk[1] = min(M, budget // bs + 40)
+        seq = nblk * bs
+        tables = torch.randint(0, nb, (B, M), generator=g, dtype=torch.int32)
+        width = M + 2
+        scores = torch.rand(B, width, generator=g)
+        rows = torch.randperm(B, generator=g).to(torch.int32)
+        counts = torch.zeros(B, dtype=torch.int32)
+        counts[rows.long()] = nblk - 1                                         # indexed by score row
+        ov = torch.tensor([3, 70, 128, 1, 127, 64][:B], dtype=torch.int32)     # around wave boundaries
+        new_scores = torch.rand(B, generator=g)
+        results = []
+        for fast in ("1", "0"):
+            monkeypatch.setenv("PE_EVICT_FAST", fast)
+            st, ct = scores.clone().cuda(), counts.clone().cuda()
+            kw = dict(victim_override=ov.cuda(), drop_victim_score=True, score_table=st, score_counts=ct,
+                      score_rows=rows.cuda(), new_scores=new_scores.cuda())
+            if inplace:
+                tb, nbk, kvl = tables.clone().cuda(), nblk.clone().cuda(), (seq.clone() - 1).cuda()
+                rmv, freed, zero = ops.evict_select_compact_inplace(tb, nbk, kvl, seq.cuda(), B, "global",
+                                                                    budget, bs, -1, **kw)
+                out = [rmv, freed, tb, nbk, kvl, st, ct]
+            else:
+                rmv, tabs, zero = ops.evict_select_compact(tables.cuda(), seq.cuda(), nblk.cuda(), "global",
+                                                           budget, bs, -1, out_width=M, **kw)
+                out = [rmv, tabs, st, ct]
+            torch.cuda.synchronize()
+            results.append([t.cpu() for t in out])
+        for a, b in zip(*results):
+            assert torch.equal(a, b), (B, M)
+        assert results[0][0].tolist() == ov.tolist()
+        # and against a plain model of the list: append the new score, delete the victim's entry
+        st = results[0][-2]
+        for i in range(B):
+            r = int(rows[i])
+            want = scores[r, :int(counts[r])].tolist() + [float(new_scores[i])]
+            del want[int(ov[i])]
+            assert st[r, :len(want)].tolist() == want and int(results[0][-1][r]) == len(want)
+    ops.check_device_diagnostics()
 
 
 def test_score_formulas_golden(ops, oracle):

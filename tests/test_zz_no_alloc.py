@@ -2,8 +2,6 @@
 workspace) against pe_paged_decode, through the C ABI: same kernels and the same split count,
 so the outputs must be bit-identical; two calls in a row, the second smaller, and a call
 whose partials exceed the built-in array must be refused without launching."""
-import os
-
 import pytest
 import torch
 
@@ -31,7 +29,7 @@ def _run_both(lib, _lib, q, kc, vc, bt, lens, kv_len):
     dt = _lib.PE_BF16 if q.dtype == torch.bfloat16 else _lib.PE_F16
     st = torch.cuda.current_stream().cuda_stream
     need = lib.pe_paged_decode_workspace_bytes(S, Hq, Hkv, D, 16, kv_len)
-    ws = torch.empty(max(need, 16), dtype=torch.uint8, device="cuda")
+    ws = torch.zeros(max(need, 16), dtype=torch.uint8, device="cuda")   # the ABI asks for a zeroed one
     out_a = torch.full_like(q, float("nan"))
     out_b = torch.full_like(q, float("nan"))
     args = (q.data_ptr(), kc.data_ptr(), vc.data_ptr(), bt.data_ptr(), lens.data_ptr(), None, S, Hq,
@@ -45,7 +43,7 @@ def _run_both(lib, _lib, q, kc, vc, bt, lens, kv_len):
 def test_noalloc_decode_matches_workspace_entry_point(oracle):
     from vllm_paged_compression_amd import _lib
     lib = _lib.load()
-    assert lib.pe_paged_decode_noalloc_max_bytes() == 8 << 20
+    assert lib.pe_paged_decode_noalloc_max_bytes() == 8 << 20   # also resolves this device's array
     # first call: 3 sequences of up to 4104 tokens -> several KV splits (partials in the array);
     # second call, right after it: fewer, shorter sequences (fewer splits, smaller partials) - it
     # must not see anything the first call left in the array
@@ -65,7 +63,45 @@ def test_noalloc_decode_matches_workspace_entry_point(oracle):
     assert torch.equal(a, b)
 
 
-def test_noalloc_decode_rejects_oversized_partials():
+def test_noalloc_decode_allocates_nothing_and_runs_under_graph_capture():
+    """Device memory in use does not change across calls (hipMemGetInfo through torch), and a call
+    captured into a HIP graph replays to the bits of the eager call."""
+    from vllm_paged_compression_amd import _lib
+    lib = _lib.load()
+    lib.pe_paged_decode_noalloc_max_bytes()          # set-up call, outside capture
+    q, kc, vc, bt, lens = _case(3, 4104, 32, 8, 128, 5)
+    S, Hq, D = q.shape
+    args = (q.data_ptr(), kc.data_ptr(), vc.data_ptr(), bt.data_ptr(), lens.data_ptr(), None, S, Hq,
+            8, D, 16, bt.shape[1], q.stride(0), kc.stride(0), kc.stride(1), D ** -0.5, 4104, _lib.PE_BF16)
+    eager = torch.full_like(q, float("nan"))
+    replayed = torch.full_like(q, float("nan"))
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(3):
+        _lib.check(lib.pe_paged_decode_noalloc(eager.data_ptr(), *args, torch.cuda.current_stream().cuda_stream),
+                   "paged_decode_noalloc")
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free1 == free0, f"device memory in use changed by {free0 - free1} bytes across the calls"
+    side = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            _lib.check(lib.pe_paged_decode_noalloc(replayed.data_ptr(), *args, side.cuda_stream),
+                       "paged_decode_noalloc under capture")
+    for _ in range(2):
+        replayed.fill_(float("nan"))
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(replayed, eager)
+    # a stream of another device than the current one is refused (one-GPU boxes cannot show it)
+    if torch.cuda.device_count() > 1:
+        other = torch.cuda.Stream(device=1)
+        rc = lib.pe_paged_decode_noalloc(eager.data_ptr(), *args, other.cuda_stream)
+        assert rc == 1 and b"is current" in lib.pe_last_error()
+
+
+def test_noalloc_decode_rejects_oversized_partials(monkeypatch):
     from vllm_paged_compression_amd import _lib
     lib = _lib.load()
     S, kv = 40, 16400
@@ -75,18 +111,11 @@ def test_noalloc_decode_rejects_oversized_partials():
     bt = torch.zeros(S, 1025, dtype=torch.int32, device="cuda")
     lens = torch.ones(S, dtype=torch.int32, device="cuda")
     out = torch.zeros_like(q)
-    old = os.environ.get("PE_DECODE_SPLITS")
-    os.environ["PE_DECODE_SPLITS"] = "64"   # 64 x 40 x 32 x 130 x 4 B = 42.6 MB of partials
-    try:
-        rc = lib.pe_paged_decode_noalloc(
-            out.data_ptr(), q.data_ptr(), kc.data_ptr(), vc.data_ptr(), bt.data_ptr(), lens.data_ptr(),
-            None, S, 32, 8, 128, 16, 1025, q.stride(0), kc.stride(0), kc.stride(1), 128 ** -0.5, kv,
-            _lib.PE_BF16, torch.cuda.current_stream().cuda_stream)
-    finally:
-        if old is None:
-            del os.environ["PE_DECODE_SPLITS"]
-        else:
-            os.environ["PE_DECODE_SPLITS"] = old
+    monkeypatch.setenv("PE_DECODE_SPLITS", "64")   # 64 x 40 x 32 x 130 x 8 B = 85 MB of partials
+    rc = lib.pe_paged_decode_noalloc(
+        out.data_ptr(), q.data_ptr(), kc.data_ptr(), vc.data_ptr(), bt.data_ptr(), lens.data_ptr(),
+        None, S, 32, 8, 128, 16, 1025, q.stride(0), kc.stride(0), kc.stride(1), 128 ** -0.5, kv,
+        _lib.PE_BF16, torch.cuda.current_stream().cuda_stream)
     assert rc == 4, rc   # PE_ERR_WORKSPACE
     assert b"exceed the built-in scratch" in lib.pe_last_error()
     torch.cuda.synchronize()

@@ -1,6 +1,6 @@
 """Sweep of the decode kernel's launch shape (waves per workgroup x KV splits) over batch shapes:
-prints us per launch for every combination (PE_DECODE_WAVES / PE_DECODE_SPLITS are read at every
-call, so one process covers the sweep).  '0/0' is the library's own choice."""
+prints us per launch for every combination (the library re-reads PE_DECODE_WAVES / PE_DECODE_SPLITS
+after ops.reload_env(), so one process covers the sweep).  '0/0' is the library's own choice."""
 import os
 import sys
 
@@ -38,6 +38,7 @@ def time_shape(B, Hq, Hkv, D, kv, layers=8, iters=20):
     for w, s in COMBOS:
         os.environ["PE_DECODE_WAVES"] = str(w)
         os.environ["PE_DECODE_SPLITS"] = str(s)
+        ops.reload_env()
 
         def run(i):
             kc, vc = caches[i % layers]

@@ -16,6 +16,7 @@ PE_F32, PE_F16, PE_BF16 = 0, 1, 2
 SIGNATURES = {
     "pe_last_error": (ctypes.c_char_p, []),
     "pe_version": (c_int, []),
+    "pe_reload_env": (None, []),
     "pe_device_diagnostics": (c_int, [c_void_p, c_int]),
     "pe_reshape_and_cache": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                      c_int64, c_int64, c_void_p, c_int, c_void_p, c_int64, c_int,
@@ -86,10 +87,13 @@ SIGNATURES = {
     "pe_ar_open_ipc_handle": (c_int, [c_void_p, c_void_p]),
     "pe_ar_close_ipc_handle": (c_int, [c_void_p]),
     "pe_ar_timeouts": (c_int, [c_void_p, c_void_p]),
+    "pe_ar_status_alloc": (c_int, [c_void_p]),
+    "pe_ar_status_free": (c_int, [c_void_p]),
+    "pe_ar_selfcheck": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "pe_allreduce_oneshot": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int, c_int,
-                                     c_int64, ctypes.c_uint, c_void_p]),
+                                     c_int64, ctypes.c_uint, c_void_p, c_int64, c_void_p]),
     "pe_allreduce_twostage": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int, c_int,
-                                     c_int64, ctypes.c_uint, c_void_p]),
+                                      c_int64, ctypes.c_uint, c_void_p, c_int64, c_void_p]),
     "pe_zero_slots_layers": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_int,
                                      c_int64, c_int, c_void_p]),
     "pe_copy_blocks": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int,

@@ -173,7 +173,7 @@ class BatchEvictionScheduler:
             self.num_cached[row] = n * bs if rem == 0 else (n - 1) * bs + rem
         self._row_of_req[request_id] = row
         self._seq_of_req[request_id] = seq_id
-        self._batch_key = None
+        self._invalidate_batch()
 
     def finish_request(self, request_id: str) -> None:
         row = self._row_of_req.pop(request_id)
@@ -184,7 +184,18 @@ class BatchEvictionScheduler:
         self.n_blocks[row] = 0
         self.num_full[row] = self.num_cached[row] = 0
         self._free_rows.append(row)
+        self._invalidate_batch()
+
+    def _invalidate_batch(self) -> None:
+        """The host record changed outside a decode step (a request came or went): neither the
+        cached batch rows nor the device-resident rows may be reused, even if the next decode
+        batch lists the same request ids (an id finished and re-added, a lone request preempted
+        and recomputed) - its blocks and lengths are not the resident ones any more."""
         self._batch_key = None
+        st = self.device_state
+        if st is not None:
+            st.key = None
+            st.score_rows_key = None
 
     def get_block_table(self, request_id: str) -> List[int]:
         row = self._row_of_req[request_id]

@@ -29,8 +29,11 @@
 // 2(N-1)/N of the message over its links instead of N-1 times the message, and the bits are the
 // one-shot form's.  The result area is part of the slot, so a message of b bytes needs
 // b + ceil(b/N) bytes of it.
-// A wait that sees no flag for about two seconds gives up, records it in the header
-// (pe_ar_timeouts) and lets the launch finish: a missing peer must not hang the GPU.
+// A missing peer must neither hang the GPU nor pass for a result: a wait that sees no flag within
+// the caller's bound (default 10 s) gives up, fills this workgroup's part of the output with NaN
+// instead of a partial sum, counts the event in the buffer header (pe_ar_timeouts) and raises the
+// communicator's status word in pinned host memory (pe_ar_status_alloc), which the host reads
+// before every call without touching the device.
 #include "pe_common.h"
 
 #include <cstring>
@@ -43,7 +46,17 @@ constexpr int AR_THREADS = 256;
 constexpr int64_t AR_HEADER_BYTES = 8192;  // flags (2 KiB) + status, second flag round at 4 KiB
 constexpr int AR_FLAGS_B = 1024;           // uint32 index of the second flag round
 constexpr int AR_STATUS_WORD = AR_MAX_BLOCKS * AR_MAX_RANKS;  // uint32 index of the timeout count
-constexpr unsigned long long AR_TIMEOUT_TICKS = 200000000ull;  // s_memrealtime runs at 100 MHz
+constexpr int AR_CHECK_WORD = 1536;        // uint32 index of the mapping self-check area (512 words)
+constexpr int AR_CHECK_OWN = 256;          // words a rank fills in its own buffer; peers' words follow
+constexpr int AR_CHECK_PEER = 8;           // words every rank writes into every buffer
+constexpr int64_t AR_DEFAULT_TIMEOUT_US = 10000000;  // s_memrealtime runs at 100 MHz: 100 ticks / us
+
+// status words in pinned host memory (uint32 each): [0] != 0: a wait gave up, [1] seq of that
+// call, [2] 1 + rank of a peer that was missing
+struct ArStatus {
+  uint32_t* host;                 // device-visible address of the host words, or nullptr
+  unsigned long long timeout_ticks;
+};
 
 struct ArPeers {
   char* buf[AR_MAX_RANKS];
@@ -63,11 +76,13 @@ __device__ __forceinline__ void ar_accumulate(float* acc, const u32x4& raw) {
 
 // Raise flag[b][rank] of a flag round (uint32 index `base`) in every rank's buffer, own included,
 // and wait for every rank's flag here.  Called by all threads of the workgroup; the stores before
-// the call are made visible first.
-__device__ __forceinline__ void ar_flag_round(const ArPeers& peers, int base, int b, int rank,
-                                              int world, uint32_t seq) {
+// the call are made visible first.  Returns false (to every thread) when a peer's flag did not
+// arrive in time.
+__device__ __forceinline__ bool ar_flag_round(const ArPeers& peers, int base, int b, int rank,
+                                              int world, uint32_t seq, const ArStatus& status) {
   __threadfence_system();
   __syncthreads();
+  int gave_up = 0;
   if ((int)threadIdx.x < world) {
     uint32_t* theirs =
         reinterpret_cast<uint32_t*>(peers.buf[threadIdx.x]) + base + b * AR_MAX_RANKS + rank;
@@ -77,14 +92,30 @@ __device__ __forceinline__ void ar_flag_round(const ArPeers& peers, int base, in
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     // flags only grow: a peer that is already one call ahead has raised a larger value
     while ((int32_t)(__hip_atomic_load(here, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
-      if (__builtin_amdgcn_s_memrealtime() - t0 > AR_TIMEOUT_TICKS) {
+      if (__builtin_amdgcn_s_memrealtime() - t0 > status.timeout_ticks) {
+        gave_up = 1;
         atomicAdd(reinterpret_cast<uint32_t*>(peers.buf[rank]) + AR_STATUS_WORD, 1u);
+        if (status.host != nullptr) {
+          __hip_atomic_store(status.host + 1, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(status.host + 2, (uint32_t)threadIdx.x + 1u, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(status.host, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         break;
       }
       __builtin_amdgcn_s_sleep(2);
     }
   }
-  __syncthreads();
+  return __syncthreads_or(gave_up) == 0;
+}
+
+// 16 bytes of quiet NaNs of the element type: what a workgroup stores instead of a sum it could
+// not complete
+template <typename T>
+__device__ __forceinline__ u32x4 ar_poison() {
+  const uint32_t w = sizeof(T) == 4 ? 0x7fc00000u
+                                    : (Traits<T>::code == PE_BF16 ? 0x7fc07fc0u : 0x7e007e00u);
+  return u32x4{w, w, w, w};
 }
 
 // sum of vector i of all ranks' input slots, rank order, f32
@@ -113,9 +144,9 @@ __device__ __forceinline__ u32x4 ar_sum_ranks(const ArPeers& peers, int64_t slot
 
 template <typename T>
 __global__ __launch_bounds__(AR_THREADS) void allreduce_twostage_kernel(
-    T* __restrict__ out, const T* __restrict__ in, int64_t n_vec /* 16-byte vectors */,
+    T* out, const T* in /* may be out */, int64_t n_vec /* 16-byte vectors */,
     int64_t chunk_vec /* vectors per rank chunk */, ArPeers peers, int rank, int world,
-    int64_t slot_bytes, uint32_t seq) {
+    int64_t slot_bytes, uint32_t seq, ArStatus status) {
   const int b = blockIdx.x;
   const int64_t per_block = (chunk_vec + gridDim.x - 1) / gridDim.x;
   const int64_t slot_off = AR_HEADER_BYTES + (int64_t)(seq & 1u) * slot_bytes;
@@ -130,30 +161,32 @@ __global__ __launch_bounds__(AR_THREADS) void allreduce_twostage_kernel(
   const u32x4* src = reinterpret_cast<const u32x4*>(in);
   for (int c = 0; c < world; ++c)
     for (int64_t i = lo_of(c) + threadIdx.x; i < hi_of(c); i += AR_THREADS) mine[i] = src[i];
-  ar_flag_round(peers, 0, b, rank, world, seq);
+  const bool ok1 = ar_flag_round(peers, 0, b, rank, world, seq, status);
   // 2. reduce this rank's chunk: into the result area for the peers, and straight into out
+  //    (a round that gave up publishes NaN, so the peers that collect this chunk see it too)
   u32x4* dst = reinterpret_cast<u32x4*>(out);
   u32x4* res = reinterpret_cast<u32x4*>(peers.buf[rank] + res_off);
   const int64_t c0 = (int64_t)rank * chunk_vec;
   for (int64_t i = lo_of(rank) + threadIdx.x; i < hi_of(rank); i += AR_THREADS) {
-    const u32x4 v = ar_sum_ranks<T>(peers, slot_off, i, world);
+    const u32x4 v = ok1 ? ar_sum_ranks<T>(peers, slot_off, i, world) : ar_poison<T>();
     res[i - c0] = v;
     dst[i] = v;
   }
-  ar_flag_round(peers, AR_FLAGS_B, b, rank, world, seq);
+  const bool ok2 = ar_flag_round(peers, AR_FLAGS_B, b, rank, world, seq, status);
   // 3. collect the other ranks' reduced chunks
   for (int c = 0; c < world; ++c) {
     if (c == rank) continue;
     const u32x4* theirs = reinterpret_cast<const u32x4*>(peers.buf[c] + res_off);
     const int64_t cc = (int64_t)c * chunk_vec;
-    for (int64_t i = lo_of(c) + threadIdx.x; i < hi_of(c); i += AR_THREADS) dst[i] = theirs[i - cc];
+    for (int64_t i = lo_of(c) + threadIdx.x; i < hi_of(c); i += AR_THREADS)
+      dst[i] = ok2 ? theirs[i - cc] : ar_poison<T>();
   }
 }
 
 template <typename T>
 __global__ __launch_bounds__(AR_THREADS) void allreduce_oneshot_kernel(
-    T* __restrict__ out, const T* __restrict__ in, int64_t n_vec /* 16-byte vectors */,
-    ArPeers peers, int rank, int world, int64_t slot_bytes, uint32_t seq) {
+    T* out, const T* in /* may be out */, int64_t n_vec /* 16-byte vectors */, ArPeers peers,
+    int rank, int world, int64_t slot_bytes, uint32_t seq, ArStatus status) {
   const int b = blockIdx.x;
   const int64_t per_block = (n_vec + gridDim.x - 1) / gridDim.x;
   const int64_t lo = b * per_block;
@@ -165,11 +198,53 @@ __global__ __launch_bounds__(AR_THREADS) void allreduce_oneshot_kernel(
   const u32x4* src = reinterpret_cast<const u32x4*>(in);
   for (int64_t i = lo + threadIdx.x; i < hi; i += AR_THREADS) mine[i] = src[i];
   // 2. raise flag[b][rank] in every rank's buffer (own included), 3. wait for all of them here
-  ar_flag_round(peers, 0, b, rank, world, seq);
+  const bool ok = ar_flag_round(peers, 0, b, rank, world, seq, status);
   // 4. sum the N slices in rank order (identical on every rank), f32 accumulation
   u32x4* dst = reinterpret_cast<u32x4*>(out);
   for (int64_t i = lo + threadIdx.x; i < hi; i += AR_THREADS)
-    dst[i] = ar_sum_ranks<T>(peers, slot_off, i, world);
+    dst[i] = ok ? ar_sum_ranks<T>(peers, slot_off, i, world) : ar_poison<T>();
+}
+
+// Mapping self-check, run once when a communicator is set up.  phase 0: every rank fills the own
+// part of its check area with a rank-tagged pattern and writes AR_CHECK_PEER tagged words into
+// every rank's buffer THROUGH THE MAPPING (what the flag writes of the exchange do).  The host
+// then synchronises all ranks.  phase 1: every rank reads every peer's own pattern through the
+// mapping (what the slot reads do) and, in its own buffer, the words each peer wrote; mismatches
+// are counted into *bad_out.
+__device__ __forceinline__ uint32_t ar_check_pattern(int writer, int target, int j) {
+  return 0xa5000000u ^ ((uint32_t)writer << 20) ^ ((uint32_t)target << 16) ^ (uint32_t)(j * 2654435761u >> 16);
+}
+__global__ __launch_bounds__(AR_THREADS) void allreduce_selfcheck_kernel(ArPeers peers, int rank, int world,
+                                                                         int phase, uint32_t* bad_out) {
+  const int t = threadIdx.x;
+  if (phase == 0) {
+    uint32_t* own = reinterpret_cast<uint32_t*>(peers.buf[rank]) + AR_CHECK_WORD;
+    if (t < AR_CHECK_OWN)
+      __hip_atomic_store(own + t, ar_check_pattern(rank, rank, t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (t < world * AR_CHECK_PEER) {
+      const int r = t / AR_CHECK_PEER, k = t % AR_CHECK_PEER;
+      uint32_t* theirs = reinterpret_cast<uint32_t*>(peers.buf[r]) + AR_CHECK_WORD + AR_CHECK_OWN +
+                         rank * AR_CHECK_PEER + k;
+      __hip_atomic_store(theirs, ar_check_pattern(rank, r, k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __threadfence_system();
+    return;
+  }
+  int bad = 0;
+  for (int r = 0; r < world; ++r) {
+    const uint32_t* theirs = reinterpret_cast<const uint32_t*>(peers.buf[r]) + AR_CHECK_WORD;
+    if (t < AR_CHECK_OWN &&
+        __hip_atomic_load(theirs + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != ar_check_pattern(r, r, t))
+      bad = 1;
+  }
+  if (t < world * AR_CHECK_PEER) {
+    const int r = t / AR_CHECK_PEER, k = t % AR_CHECK_PEER;
+    const uint32_t* mine = reinterpret_cast<const uint32_t*>(peers.buf[rank]) + AR_CHECK_WORD +
+                           AR_CHECK_OWN + r * AR_CHECK_PEER + k;
+    if (__hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != ar_check_pattern(r, rank, k))
+      bad = 1;
+  }
+  if (bad) atomicAdd(bad_out, 1u);
 }
 
 }  // namespace pe
@@ -243,9 +318,64 @@ int pe_ar_timeouts(const void* own_buffer, unsigned int* count_out) {
   return PE_OK;
 }
 
+int pe_ar_status_alloc(void** host_words_out) {
+  using namespace pe;
+  PE_REQUIRE(host_words_out, PE_ERR_INVALID_ARG, "ar_status_alloc: null pointer");
+  void* p = nullptr;
+  hipError_t e = hipHostMalloc(&p, 64, hipHostMallocMapped);
+  if (e != hipSuccess) return fail(PE_ERR_LAUNCH, "ar_status_alloc: %s", hipGetErrorString(e));
+  memset(p, 0, 64);
+  *host_words_out = p;
+  return PE_OK;
+}
+
+int pe_ar_status_free(void* host_words) {
+  using namespace pe;
+  if (host_words == nullptr) return PE_OK;
+  hipError_t e = hipHostFree(host_words);
+  if (e != hipSuccess) return fail(PE_ERR_LAUNCH, "ar_status_free: %s", hipGetErrorString(e));
+  return PE_OK;
+}
+
+namespace pe {
+// the kernels' view of the caller's status words and wait bound
+static int ar_status(void* status_host, int64_t timeout_us, ArStatus* st) {
+  st->host = nullptr;
+  if (status_host != nullptr) {
+    void* d = nullptr;
+    hipError_t e = hipHostGetDevicePointer(&d, status_host, 0);
+    if (e != hipSuccess)
+      return fail(PE_ERR_INVALID_ARG, "allreduce: status words are not mapped pinned host memory (%s)",
+                  hipGetErrorString(e));
+    st->host = static_cast<uint32_t*>(d);
+  }
+  if (timeout_us <= 0) timeout_us = AR_DEFAULT_TIMEOUT_US;
+  st->timeout_ticks = (unsigned long long)timeout_us * 100ull;
+  return PE_OK;
+}
+}  // namespace pe
+
+int pe_ar_selfcheck(void* const* peer_buffers, int rank, int world, int phase,
+                    unsigned int* mismatches_dev, void* stream) {
+  using namespace pe;
+  PE_REQUIRE(peer_buffers && world >= 1 && world <= AR_MAX_RANKS && rank >= 0 && rank < world,
+             PE_ERR_INVALID_ARG, "ar_selfcheck: bad arguments");
+  PE_REQUIRE(phase == 0 || (phase == 1 && mismatches_dev), PE_ERR_INVALID_ARG,
+             "ar_selfcheck: phase 0 writes, phase 1 verifies into mismatches_dev");
+  ArPeers peers;
+  for (int r = 0; r < AR_MAX_RANKS; ++r) peers.buf[r] = nullptr;
+  for (int r = 0; r < world; ++r) {
+    PE_REQUIRE(peer_buffers[r] != nullptr, PE_ERR_INVALID_ARG, "ar_selfcheck: peer buffer %d is null", r);
+    peers.buf[r] = static_cast<char*>(peer_buffers[r]);
+  }
+  hipLaunchKernelGGL(allreduce_selfcheck_kernel, dim3(1), dim3(AR_THREADS), 0,
+                     static_cast<hipStream_t>(stream), peers, rank, world, phase, mismatches_dev);
+  return check_launch("ar_selfcheck");
+}
+
 int pe_allreduce_oneshot(void* out, const void* in, int64_t count, int dtype,
                          void* const* peer_buffers, int rank, int world, int64_t buffer_bytes,
-                         unsigned int seq, void* stream) {
+                         unsigned int seq, void* status_host, int64_t timeout_us, void* stream) {
   using namespace pe;
   PE_REQUIRE(count >= 0, PE_ERR_INVALID_ARG, "allreduce: negative count");
   if (count == 0) return PE_OK;
@@ -267,6 +397,8 @@ int pe_allreduce_oneshot(void* out, const void* in, int64_t count, int dtype,
     PE_REQUIRE(peer_buffers[r] != nullptr, PE_ERR_INVALID_ARG, "allreduce: peer buffer %d is null", r);
     peers.buf[r] = static_cast<char*>(peer_buffers[r]);
   }
+  ArStatus status;
+  if (int rc = ar_status(status_host, timeout_us, &status)) return rc;
   const int64_t n_vec = bytes / 16;
   // one workgroup per 16 KiB, at most AR_MAX_BLOCKS: the slice boundaries are the same on all ranks
   int blocks = (int)((n_vec + 1023) / 1024);
@@ -275,13 +407,14 @@ int pe_allreduce_oneshot(void* out, const void* in, int64_t count, int dtype,
   PE_DISPATCH_ALL(dtype, T,
                   hipLaunchKernelGGL(allreduce_oneshot_kernel<T>, dim3((unsigned)blocks),
                                      dim3(AR_THREADS), 0, static_cast<hipStream_t>(stream), (T*)out,
-                                     (const T*)in, n_vec, peers, rank, world, slot, (uint32_t)seq));
+                                     (const T*)in, n_vec, peers, rank, world, slot, (uint32_t)seq,
+                                     status));
   return check_launch("allreduce_oneshot");
 }
 
 int pe_allreduce_twostage(void* out, const void* in, int64_t count, int dtype,
                           void* const* peer_buffers, int rank, int world, int64_t buffer_bytes,
-                          unsigned int seq, void* stream) {
+                          unsigned int seq, void* status_host, int64_t timeout_us, void* stream) {
   using namespace pe;
   PE_REQUIRE(count >= 0, PE_ERR_INVALID_ARG, "allreduce: negative count");
   if (count == 0) return PE_OK;
@@ -305,6 +438,8 @@ int pe_allreduce_twostage(void* out, const void* in, int64_t count, int dtype,
     PE_REQUIRE(peer_buffers[r] != nullptr, PE_ERR_INVALID_ARG, "allreduce: peer buffer %d is null", r);
     peers.buf[r] = static_cast<char*>(peer_buffers[r]);
   }
+  ArStatus status;
+  if (int rc = ar_status(status_host, timeout_us, &status)) return rc;
   // one workgroup per 16 KiB of a chunk, at most AR_MAX_BLOCKS
   int blocks = (int)((chunk_vec + 1023) / 1024);
   if (blocks < 1) blocks = 1;
@@ -313,7 +448,7 @@ int pe_allreduce_twostage(void* out, const void* in, int64_t count, int dtype,
                   hipLaunchKernelGGL(allreduce_twostage_kernel<T>, dim3((unsigned)blocks),
                                      dim3(AR_THREADS), 0, static_cast<hipStream_t>(stream), (T*)out,
                                      (const T*)in, n_vec, chunk_vec, peers, rank, world, slot,
-                                     (uint32_t)seq));
+                                     (uint32_t)seq, status));
   return check_launch("allreduce_twostage");
 }
 

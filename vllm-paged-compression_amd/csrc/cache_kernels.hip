@@ -6,12 +6,17 @@
 // All of it is HBM-bound byte movement: the kernels are organised so that global loads
 // and stores are 16 bytes per lane and contiguous across a wave wherever the paged
 // layout allows it.
+#include <atomic>
+
 #include "pe_common.h"
 
 namespace pe {
 
 thread_local char g_last_error[512] = "";
 char* last_error_buf() { return g_last_error; }
+
+static std::atomic<int> g_env_generation{0};
+int env_generation() { return g_env_generation.load(std::memory_order_relaxed); }
 
 constexpr int RC_TOKENS = 16;   // tokens per workgroup tile
 constexpr int RC_THREADS = 256;
@@ -248,7 +253,8 @@ __global__ void copy_blocks_kernel(void* const* __restrict__ key_ptrs,
 extern "C" {
 
 const char* pe_last_error(void) { return pe::g_last_error; }
-int pe_version(void) { return 104; }  // 104: score formulas (pe_score_formula), PE_SCORE_KEY_CACHE
+int pe_version(void) { return 105; }  // 105: pe_reload_env, in-launch split merge, all-reduce status word
+void pe_reload_env(void) { pe::g_env_generation.fetch_add(1, std::memory_order_relaxed); }
 
 int pe_device_diagnostics(unsigned int* flags_out, int reset) {
   PE_REQUIRE(flags_out != nullptr, PE_ERR_INVALID_ARG, "device_diagnostics: null pointer");

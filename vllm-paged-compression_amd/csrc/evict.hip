@@ -557,6 +557,9 @@ __global__ __launch_bounds__(SCORE_THREADS) void evict_select_fast_kernel(
         if (bi != 0x7fffffff) best = bi;
       }
       rmv = best;
+      // every thread holds its list entries in registers before any of them is overwritten (with
+      // a caller-chosen victim and caller-supplied scores no barrier lies on the way to here)
+      __syncthreads();
       if (drop_victim_score && best < n) {
         // delete the victim's entry: every entry behind it moves one place to the front
 #pragma unroll
@@ -734,8 +737,8 @@ static int evict_select_impl(int32_t* rmv_idx_out, int32_t* out_tables, int64_t*
     }
   }
   // PE_EVICT_FAST=0 sends every call through the general kernel (differential tests)
-  const char* fast_env = getenv("PE_EVICT_FAST");
-  const bool fast_ok = fast_env == nullptr || atoi(fast_env) != 0;
+  static EnvInt fast_env("PE_EVICT_FAST", 1);
+  const bool fast_ok = fast_env.get() != 0;
   if (fast_ok && !compat_q1 && max_blocks <= FAST_SLOTS * SCORE_THREADS &&
       score_table_width <= FAST_SLOTS * SCORE_THREADS) {
     PE_DISPATCH_ALL(dtype, T,

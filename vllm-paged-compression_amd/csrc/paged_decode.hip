@@ -67,8 +67,29 @@ struct RopeArgs {
   int64_t max_position;
 };
 
-// Partial results of one split: [split][seq][head] -> m, l, then O[D] (all f32)
+// Partial results of one split: [split][seq][head] -> m, l, then O[D]; one 64-bit word each
+// (f32 value in the low half, the ready tag of the in-launch merge in the high half)
 __host__ __device__ inline int64_t ws_stride(int head_size) { return head_size + 2; }
+constexpr int64_t WS_WORD = 8;
+
+// Split-KV partials carry their own "ready" signal when the splits are merged inside the launch:
+// a word is {f32 value, MERGE_TAG}, written and read as one 64-bit device-scope atomic (relaxed:
+// the value and its tag travel together, so no fence and no separate flag round trip is needed),
+// and cleared by the merging workgroup once read.  The workspace must therefore hold no
+// MERGE_TAG words before its first use (zero-filled by the caller) - see include/paged_evict.h.
+constexpr uint32_t MERGE_TAG = 0x5ea1ed01u;
+constexpr unsigned long long MERGE_TIMEOUT_TICKS = 200000000ull;  // 2 s of the 100 MHz clock
+__device__ __forceinline__ void ws_publish(uint64_t* p, float v) {
+  __hip_atomic_store(p, ((uint64_t)MERGE_TAG << 32) | (uint64_t)__float_as_uint(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint64_t ws_peek(const uint64_t* p) {
+  return __hip_atomic_load(const_cast<uint64_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool ws_tagged(uint64_t v) { return (uint32_t)(v >> 32) == MERGE_TAG; }
+__device__ __forceinline__ void ws_clear(uint64_t* p) {
+  __hip_atomic_store(p, (uint64_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // WAVES: waves per workgroup.  4 (two workgroups per CU) is the throughput shape; 8 and 16 are
 // the latency shapes for launches with few (sequence, KV head) pairs: the block pairs of a
@@ -100,7 +121,7 @@ void paged_decode_mfma_kernel(
     const T* __restrict__ new_value, const int64_t* __restrict__ new_slots, int64_t new_k_stride,
     int64_t new_v_stride, int64_t num_slots, T* key_cache_w, T* value_cache_w,
     const int64_t* __restrict__ rope_positions, const T* __restrict__ rope_cos_sin, int rot_dim,
-    int rope_neox, int64_t rope_max_position) {
+    int rope_neox, int64_t rope_max_position, int merge_in_launch) {
   // key_cache_w / value_cache_w: the same caches through non-restrict pointers, used only by
   // the fused KV write (the written slot is never loaded by this launch).
   using TR = Traits<T>;
@@ -505,8 +526,17 @@ void paged_decode_mfma_kernel(
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < gqa * HEAD_SIZE; i += WAVES * 64) {
-    const int h = i / HEAD_SIZE, d = i % HEAD_SIZE;
+  // Every thread owns one (head, d) element per round; the rounds are workgroup-uniform because
+  // the merging workgroup synchronises inside them.
+  constexpr int NT = WAVES * 64;
+  const int total = gqa * HEAD_SIZE;
+  const bool merger = merge_in_launch != 0 && num_splits > 1 && split == num_splits - 1;
+  uint64_t* ws64 = reinterpret_cast<uint64_t*>(ws);
+  const int64_t wstride = ws_stride(HEAD_SIZE);
+  for (int base = 0; base < total; base += NT) {
+    const int i = base + (int)threadIdx.x;
+    const bool active = i < total;
+    const int h = active ? i / HEAD_SIZE : 0, d = active ? i % HEAD_SIZE : 0;
     float m_tot = sm_m[h];
 #pragma unroll
     for (int w = 1; w < WAVES; ++w) m_tot = fmaxf(m_tot, sm_m[w * 16 + h]);
@@ -518,47 +548,128 @@ void paged_decode_mfma_kernel(
       l += f * sm_l[w * 16 + h];
     }
     const int head = kvh * gqa + h;
+    T* dst = out + ((int64_t)seq * num_heads + head) * HEAD_SIZE + d;
     if (num_splits == 1) {
-      out[((int64_t)seq * num_heads + head) * HEAD_SIZE + d] = (T)(o * (1.f / (l + 1e-6f)));
-    } else {
-      float* w = ws + (((int64_t)split * num_seqs + seq) * num_heads + head) * ws_stride(HEAD_SIZE);
-      if (d == 0) {
-        w[0] = m_tot;
-        w[1] = l;
+      if (active) *dst = (T)(o * (1.f / (l + 1e-6f)));
+      continue;
+    }
+    if (!merger) {
+      // partial of this split: 64-bit words {f32 value, tag}.  With the merge inside the launch
+      // the words are device-scope atomic stores that carry MERGE_TAG: the reader needs no
+      // other signal than the word itself.
+      if (active) {
+        uint64_t* w = ws64 + (((int64_t)split * num_seqs + seq) * num_heads + head) * wstride;
+        if (merge_in_launch) {
+          if (d == 0) {
+            ws_publish(w, m_tot);
+            ws_publish(w + 1, l);
+          }
+          ws_publish(w + 2 + d, o);
+        } else {
+          if (d == 0) {
+            w[0] = (uint64_t)__float_as_uint(m_tot);
+            w[1] = (uint64_t)__float_as_uint(l);
+          }
+          w[2 + d] = (uint64_t)__float_as_uint(o);
+        }
       }
-      w[2 + d] = o;
+      continue;
+    }
+    // The last split of a (sequence, KV head) merges: it was dispatched behind its siblings
+    // (blockIdx.x runs fastest), so all of them are resident or done and none of them ever
+    // waits - polling here cannot deadlock.  A thread polls exactly the words it needs.
+    float M = m_tot, acc_o = o, acc_l = l;
+    bool bad = false;
+    uint64_t* w0 = ws64 + ((int64_t)seq * num_heads + head) * wstride;
+    const int64_t split_stride = (int64_t)num_seqs * num_heads * wstride;
+    const int n_sib = num_splits - 1;
+    if (active) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      for (int s0 = 0; s0 < n_sib && !bad; s0 += 4) {
+        uint64_t vm[4], vl[4], vo[4];
+        while (true) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const uint64_t* w = w0 + (int64_t)min(s0 + k, n_sib - 1) * split_stride;
+            vm[k] = ws_peek(w);
+            vl[k] = ws_peek(w + 1);
+            vo[k] = ws_peek(w + 2 + d);
+          }
+          bool ready = true;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) ready = ready && ws_tagged(vm[k]) && ws_tagged(vl[k]) && ws_tagged(vo[k]);
+          if (ready) break;
+          if (__builtin_amdgcn_s_memrealtime() - t0 > MERGE_TIMEOUT_TICKS) {
+            bad = true;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (bad) break;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (s0 + k < n_sib) {
+            const float ms = __uint_as_float((uint32_t)vm[k]);
+            const float m_new = fmaxf(M, ms);
+            const float fa = __expf(M - m_new), fb = __expf(ms - m_new);
+            acc_o = acc_o * fa + __uint_as_float((uint32_t)vo[k]) * fb;
+            acc_l = acc_l * fa + __uint_as_float((uint32_t)vl[k]) * fb;
+            M = m_new;
+          }
+        }
+      }
+    }
+    __syncthreads();  // every thread of the round has read its words: clear them for the next launch
+    if (active) {
+      if (!bad) {
+        for (int s = 0; s < n_sib; ++s) {
+          uint64_t* w = w0 + (int64_t)s * split_stride;
+          ws_clear(w + 2 + d);
+          if (d == 0) {
+            ws_clear(w);
+            ws_clear(w + 1);
+          }
+        }
+        *dst = (T)(acc_o * (1.f / (acc_l + 1e-6f)));
+      } else {
+        // a sibling never delivered (a bug or a dying launch): poison instead of a partial sum
+        *dst = (T)__uint_as_float(0x7fc00000u);
+        atomicOr(&decode_diag_word, (unsigned)PE_DIAG_DECODE_MERGE_TIMEOUT);
+      }
     }
   }
 }
 
-// merge of the split partials: grid (num_heads, num_seqs), one thread per d.  All partials of
-// a thread are requested before any is used (one memory round trip instead of one per pass).
-template <typename T, int MAX_SPLITS>
-__global__ void paged_decode_merge_kernel(T* __restrict__ out, const float* __restrict__ ws,
+// Merge of the split partials in a launch of its own (PE_DECODE_MERGE=launch; the default merges
+// inside the attention launch): grid (num_heads, num_seqs), one thread per d.  Eight splits'
+// words are requested before any is used.
+template <typename T>
+__global__ void paged_decode_merge_kernel(T* __restrict__ out, const uint64_t* __restrict__ ws,
                                           int num_heads, int head_size, int num_splits) {
   const int head = blockIdx.x, seq = blockIdx.y, num_seqs = gridDim.y;
   const int64_t stride = ws_stride(head_size);
   const int64_t split_stride = (int64_t)num_seqs * num_heads * stride;
-  const float* base = ws + ((int64_t)seq * num_heads + head) * stride;
+  const uint64_t* base = ws + ((int64_t)seq * num_heads + head) * stride;
   for (int d = threadIdx.x; d < head_size; d += blockDim.x) {
-    float m[MAX_SPLITS], l[MAX_SPLITS], o[MAX_SPLITS];
+    float M = NEG_BIG, acc = 0.f, lsum = 0.f;
+    for (int s0 = 0; s0 < num_splits; s0 += 8) {
+      float m[8], l[8], o[8];
 #pragma unroll
-    for (int s = 0; s < MAX_SPLITS; ++s) {
-      const bool on = s < num_splits;
-      const float* w = base + (on ? s : 0) * split_stride;
-      m[s] = on ? w[0] : NEG_BIG;
-      l[s] = on ? w[1] : 0.f;
-      o[s] = on ? w[2 + d] : 0.f;
-    }
-    float m_tot = NEG_BIG;
+      for (int k = 0; k < 8; ++k) {
+        const bool on = s0 + k < num_splits;
+        const uint64_t* w = base + (on ? s0 + k : 0) * split_stride;
+        m[k] = on ? __uint_as_float((uint32_t)w[0]) : NEG_BIG;
+        l[k] = on ? __uint_as_float((uint32_t)w[1]) : 0.f;
+        o[k] = on ? __uint_as_float((uint32_t)w[2 + d]) : 0.f;
+      }
 #pragma unroll
-    for (int s = 0; s < MAX_SPLITS; ++s) m_tot = fmaxf(m_tot, m[s]);
-    float acc = 0.f, lsum = 0.f;
-#pragma unroll
-    for (int s = 0; s < MAX_SPLITS; ++s) {
-      const float f = __expf(m[s] - m_tot);
-      acc += f * o[s];
-      lsum += f * l[s];
+      for (int k = 0; k < 8; ++k) {
+        const float m_new = fmaxf(M, m[k]);
+        const float fa = __expf(M - m_new), fb = __expf(m[k] - m_new);
+        acc = acc * fa + o[k] * fb;
+        lsum = lsum * fa + l[k] * fb;
+        M = m_new;
+      }
     }
     out[((int64_t)seq * num_heads + head) * head_size + d] = (T)(acc * (1.f / (lsum + 1e-6f)));
   }
@@ -641,10 +752,6 @@ __global__ __launch_bounds__(256) void paged_decode_generic_kernel(
   }
 }
 
-static int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return v ? atoi(v) : dflt;
-}
 
 // Upper limit of the split count for a maximum length: a split has at least one block pair per
 // wave of the narrowest workgroup.  pe_paged_decode_workspace_bytes sizes the workspace with it
@@ -664,7 +771,8 @@ static int split_cap(int max_seq_len) {
 static int choose_splits(int num_seqs, int num_kv_heads, int max_seq_len) {
   const int n_pairs = (max_seq_len + 31) / 32;
   const int cap = split_cap(max_seq_len);
-  static const int min_pairs_env = env_int("PE_DEC_SPLIT_MIN_PAIRS", 0);
+  static EnvInt min_pairs_var("PE_DEC_SPLIT_MIN_PAIRS", 0);
+  const int min_pairs_env = min_pairs_var.get();
   const int64_t wgs = (int64_t)num_seqs * num_kv_heads;
   const int64_t target = 256;  // one workgroup per CU
   const int min_pairs = min_pairs_env > 0 ? min_pairs_env : (wgs * 4 <= target ? 12 : 24);
@@ -701,7 +809,8 @@ static void choose_shape(int num_seqs, int num_heads, int num_kv_heads, int head
   const int n_pairs = (max_seq_len + 31) / 32;
   const int cap = split_cap(max_seq_len);
   const int64_t wgs = (int64_t)num_seqs * num_kv_heads;
-  static const int64_t latency_pairs = env_int("PE_DEC_LATENCY_PAIRS", 2048);
+  static EnvInt latency_pairs_var("PE_DEC_LATENCY_PAIRS", 2048);
+  const int64_t latency_pairs = latency_pairs_var.get();
   *waves = DEC_WAVES;
   if (wgs * n_pairs <= latency_pairs && n_pairs > DEC_WAVES) {
     *waves = 8;
@@ -712,9 +821,10 @@ static void choose_shape(int num_seqs, int num_heads, int num_kv_heads, int head
   } else {
     *splits = choose_splits(num_seqs, num_kv_heads, max_seq_len);
   }
-  const int forced_w = env_int("PE_DECODE_WAVES", 0);
+  static EnvInt forced_w_var("PE_DECODE_WAVES", 0), forced_s_var("PE_DECODE_SPLITS", 0);
+  const int forced_w = forced_w_var.get();
   if (forced_w == 4 || forced_w == 8 || forced_w == 16) *waves = forced_w;
-  const int forced_s = env_int("PE_DECODE_SPLITS", 0);
+  const int forced_s = forced_s_var.get();
   if (forced_s > 0) *splits = forced_s < cap ? forced_s : cap;
   while (*waves > DEC_WAVES &&
          merge_lds_bytes(*waves, num_heads / num_kv_heads, head_size) > 64 * 1024)
@@ -724,7 +834,8 @@ static void choose_shape(int num_seqs, int num_heads, int num_kv_heads, int head
 static bool mfma_path_ok(int num_heads, int num_kv_heads, int head_size, int block_size,
                          int dtype, int64_t q_stride, int64_t kv_block_stride,
                          int64_t kv_head_stride) {
-  if (env_int("PE_DECODE_FORCE_GENERIC", 0)) return false;
+  static EnvInt force_generic("PE_DECODE_FORCE_GENERIC", 0);
+  if (force_generic.get()) return false;
   if (dtype != PE_BF16 && dtype != PE_F16) return false;
   if (block_size != 16 && block_size != 8 && block_size != 32) return false;
   if (head_size != 64 && head_size != 128 && head_size != 256) return false;
@@ -756,7 +867,7 @@ int64_t pe_paged_decode_workspace_bytes(int num_seqs, int num_heads, int num_kv_
   // sized for the largest split count choose_splits can pick, so a caller may allocate once
   const int max_splits = pe::split_cap(max_seq_len);
   if (max_splits <= 1) return 0;
-  return (int64_t)max_splits * num_seqs * num_heads * pe::ws_stride(head_size) * 4;
+  return (int64_t)max_splits * num_seqs * num_heads * pe::ws_stride(head_size) * pe::WS_WORD;
 }
 
 static int decode_impl(void* out, const void* query, const void* key_cache, const void* value_cache,
@@ -790,11 +901,16 @@ static int decode_impl(void* out, const void* query, const void* key_cache, cons
                    kv_block_stride, kv_head_stride)) {
     int splits = 1, waves = DEC_WAVES;
     choose_shape(num_seqs, num_heads, num_kv_heads, head_size, max_seq_len, &waves, &splits);
-    // the rotating form and the 8-/32-token-block forms are built for 4 and 8 waves
-    if ((rope != nullptr || block_size != 16) && waves > 8) waves = 8;
+    // the rotating form, the 8-/32-token-block forms and head size 256 (whose 16-wave form would
+    // spill) are built for 4 and 8 waves
+    if ((rope != nullptr || block_size != 16 || head_size > 128) && waves > 8) waves = 8;
+    // PE_DECODE_MERGE=launch: the split partials are merged by a second launch instead of by the
+    // last split's workgroup (A/B measurements, differential tests)
+    static EnvInt merge_launch_var("PE_DECODE_MERGE_LAUNCH", 0);
+    const int merge_in_launch = merge_launch_var.get() ? 0 : 1;
     float* ws = static_cast<float*>(workspace);
     if (splits > 1) {
-      const int64_t need = (int64_t)splits * num_seqs * num_heads * ws_stride(head_size) * 4;
+      const int64_t need = (int64_t)splits * num_seqs * num_heads * ws_stride(head_size) * WS_WORD;
       PE_REQUIRE(workspace && workspace_bytes >= need, PE_ERR_WORKSPACE,
                  "paged_decode needs %lld workspace bytes, got %lld", (long long)need,
                  (long long)workspace_bytes);
@@ -812,7 +928,8 @@ static int decode_impl(void* out, const void* query, const void* key_cache, cons
                      splits, (const T*)new_key, (const T*)new_value, new_slots, new_k_stride,       \
                      new_v_stride, num_slots, (T*)key_cache, (T*)value_cache,                      \
                      R ? rope->positions : nullptr, R ? (const T*)rope->cos_sin : nullptr,         \
-                     R ? rope->rot_dim : 0, R ? rope->is_neox : 0, R ? rope->max_position : 0)
+                     R ? rope->rot_dim : 0, R ? rope->is_neox : 0, R ? rope->max_position : 0,     \
+                     merge_in_launch)
 #define PE_LAUNCH_DEC_W(T, HS, W) PE_LAUNCH_DEC_WR(T, HS, W, false)
 #define PE_LAUNCH_DEC_B(T, HS, W, B)                                                               \
   if (lds > 64 * 1024)                                                                             \
@@ -825,7 +942,7 @@ static int decode_impl(void* out, const void* query, const void* key_cache, cons
                      max_num_blocks_per_seq, q_stride, kv_block_stride, kv_head_stride, scale,     \
                      splits, (const T*)new_key, (const T*)new_value, new_slots, new_k_stride,       \
                      new_v_stride, num_slots, (T*)key_cache, (T*)value_cache, nullptr, nullptr, 0, \
-                     0, 0)
+                     0, 0, merge_in_launch)
 #define PE_LAUNCH_DEC(T, HS)                               \
   do {                                                     \
     if (block_size != 16) {                                \
@@ -853,7 +970,9 @@ static int decode_impl(void* out, const void* query, const void* key_cache, cons
         }                                                  \
       }                                                    \
     } else if (waves == 16) {                              \
-      PE_LAUNCH_DEC_W(T, HS, 16);                          \
+      if constexpr (HS <= 128) {                           \
+        PE_LAUNCH_DEC_W(T, HS, 16);                        \
+      }                                                    \
     } else if (waves == 8) {                               \
       PE_LAUNCH_DEC_W(T, HS, 8);                           \
     } else {                                               \
@@ -870,17 +989,12 @@ static int decode_impl(void* out, const void* query, const void* key_cache, cons
 #undef PE_LAUNCH_DEC_W
 #undef PE_LAUNCH_DEC_WR
     if (int rc = check_launch("paged_decode")) return rc;
-    if (splits > 1) {
-#define PE_LAUNCH_MERGE(T, MS)                                                                   \
-  hipLaunchKernelGGL((paged_decode_merge_kernel<T, MS>), dim3((unsigned)num_heads, (unsigned)num_seqs), \
-                     dim3(head_size <= 64 ? 64 : 128), 0, st, (T*)out, ws, num_heads, head_size, splits)
-      PE_DISPATCH_16(dtype, T, {
-        if (splits <= 4) PE_LAUNCH_MERGE(T, 4);
-        else if (splits <= 8) PE_LAUNCH_MERGE(T, 8);
-        else if (splits <= 16) PE_LAUNCH_MERGE(T, 16);
-        else PE_LAUNCH_MERGE(T, 64);
-      });
-#undef PE_LAUNCH_MERGE
+    if (splits > 1 && !merge_in_launch) {
+      PE_DISPATCH_16(dtype, T,
+                     hipLaunchKernelGGL((paged_decode_merge_kernel<T>),
+                                        dim3((unsigned)num_heads, (unsigned)num_seqs),
+                                        dim3(head_size <= 64 ? 64 : 128), 0, st, (T*)out,
+                                        (const uint64_t*)ws, num_heads, head_size, splits));
       if (int rc = check_launch("paged_decode_merge")) return rc;
     }
     return PE_OK;
@@ -1017,12 +1131,22 @@ constexpr int MAX_DEVICES = 64;
 static void* noalloc_scratch_ptr[MAX_DEVICES];
 static std::mutex noalloc_mutex;
 
-// Device address of this GPU's copy of `scratch` (every device holds its own copy at its own
-// address); resolved on the first call made with that device current.
-static int noalloc_scratch(void** ptr_out) {
-  int dev = -1;
-  hipError_t e = hipGetDevice(&dev);
+// Device address of a GPU's copy of `scratch` (every device holds its own copy at its own
+// address).  The device is the one `stream` belongs to (the current device for the null stream)
+// and must be current: a symbol resolves on the current device only.  Resolved on the first call
+// per device - pe_paged_decode_noalloc_max_bytes does it at set-up, outside stream capture.
+static int noalloc_scratch(void* stream, void** ptr_out) {
+  int cur = -1;
+  hipError_t e = hipGetDevice(&cur);
   if (e != hipSuccess) return fail(PE_ERR_LAUNCH, "hipGetDevice: %s", hipGetErrorString(e));
+  int dev = cur;
+  if (stream != nullptr) {
+    e = hipStreamGetDevice(static_cast<hipStream_t>(stream), &dev);
+    if (e != hipSuccess) return fail(PE_ERR_LAUNCH, "hipStreamGetDevice: %s", hipGetErrorString(e));
+    PE_REQUIRE(dev == cur, PE_ERR_INVALID_ARG,
+               "pe_paged_decode_noalloc: the stream belongs to device %d but device %d is current",
+               dev, cur);
+  }
   PE_REQUIRE(dev >= 0 && dev < MAX_DEVICES, PE_ERR_UNSUPPORTED, "device index %d out of range", dev);
   std::lock_guard<std::mutex> lock(noalloc_mutex);
   if (noalloc_scratch_ptr[dev] == nullptr) {
@@ -1038,7 +1162,11 @@ static int noalloc_scratch(void** ptr_out) {
 }
 }  // namespace pe
 
-int64_t pe_paged_decode_noalloc_max_bytes(void) { return (int64_t)PE_NOALLOC_SCRATCH_BYTES; }
+int64_t pe_paged_decode_noalloc_max_bytes(void) {
+  void* p = nullptr;
+  (void)pe::noalloc_scratch(nullptr, &p);  // set-up: resolve the current device's array now
+  return (int64_t)PE_NOALLOC_SCRATCH_BYTES;
+}
 
 int pe_paged_decode_noalloc(void* out, const void* query, const void* key_cache,
                             const void* value_cache, const int32_t* block_tables,
@@ -1049,7 +1177,7 @@ int pe_paged_decode_noalloc(void* out, const void* query, const void* key_cache,
                             void* stream) {
   using namespace pe;
   void* ws = nullptr;
-  if (int rc = noalloc_scratch(&ws)) return rc;
+  if (int rc = noalloc_scratch(stream, &ws)) return rc;
   // decode_impl checks the partials of the split count it picks against the size given here and
   // reports PE_ERR_WORKSPACE when they do not fit; nothing in it allocates
   const int rc = decode_impl(out, query, key_cache, value_cache, block_tables, seq_lens,

@@ -5,6 +5,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 
 #include "../../include/paged_evict.h"
 
@@ -31,6 +32,28 @@ inline int check_launch(const char* what) {
 }
 
 inline int elem_size(int dtype) { return dtype == PE_F32 ? 4 : 2; }
+
+// ---- tunables from the environment, read once ------------------------------------
+// A launch path must not call getenv (a linear scan of the environment) per launch.  An EnvInt
+// reads its variable on first use and again after pe_reload_env() (tests and sweep tools that
+// change a tunable inside one process call that).
+int env_generation();  // bumped by pe_reload_env (defined in cache_kernels.hip)
+struct EnvInt {
+  const char* name;
+  int dflt;
+  int gen = -1;
+  int val = 0;
+  EnvInt(const char* n, int d) : name(n), dflt(d) {}
+  int get() {
+    const int g = env_generation();
+    if (gen != g) {
+      const char* v = getenv(name);
+      val = v ? atoi(v) : dflt;
+      gen = g;
+    }
+    return val;
+  }
+};
 
 // per-file diagnostic words behind pe_device_diagnostics (defined in paged_decode.hip / evict.hip)
 int decode_diag_fetch(unsigned int* out, int reset);

@@ -458,11 +458,8 @@ extern "C" int pe_prefill_causal(void* out, const void* q, const void* k, const 
     // 256-row shape (half the K/V tile traffic per flop) from 4096 tokens on with up to 4 query
     // heads per KV head, or from 2048 with enough tiles to fill the chip several times over;
     // everything else the 128-row default.  PE_PREFILL_SHAPE overrides (tuning runs).
-    static const int shape_env = [] {
-      const char* e = getenv("PE_PREFILL_SHAPE");
-      return e ? atoi(e) : 0;
-    }();
-    int shape = shape_env;
+    static EnvInt shape_env("PE_PREFILL_SHAPE", 0);
+    int shape = shape_env.get();
     if (shape == 0) {
       const int64_t tiles256 = (int64_t)num_seqs * num_heads * ((max_q_len + 255) / 256);
       const int64_t tiles128 = (int64_t)num_seqs * num_heads * ((max_q_len + 127) / 128);
