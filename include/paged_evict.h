@@ -74,7 +74,7 @@ typedef enum {
 
 const char* pe_last_error(void);
 int pe_version(void);
-/* Tunables read from the environment (PE_DECODE_SPLITS, PE_DECODE_WAVES, PE_DECODE_MERGE_LAUNCH,
+/* Tunables read from the environment (PE_DECODE_SPLITS, PE_DECODE_WAVES,
  * PE_EVICT_FAST, PE_PREFILL_SHAPE, ...: experiment and test switches, none is needed in
  * production) are read once, on first use, so that no launch pays for getenv.  A process that
  * changes one of them afterwards calls pe_reload_env() to have them read again. */
@@ -92,15 +92,10 @@ enum {
   PE_DIAG_SCORE_ROW_FULL = 2,     /* pe_evict_select_compact: a sequence's score row already
                                      held score_table_width entries; the new block's score was
                                      not appended                                              */
-  PE_DIAG_TABLE_STATE_MISMATCH = 4, /* pe_table_state_advance: the step's token does not fall into
+  PE_DIAG_TABLE_STATE_MISMATCH = 4 /* pe_table_state_advance: the step's token does not fall into
                                      the last block of the device-resident row (host and device
                                      counters disagree, or the row is full); the token's slot
                                      was reported as -1 (not cached)                           */
-  PE_DIAG_DECODE_MERGE_TIMEOUT = 8 /* pe_paged_decode / pe_decode_step: the workgroup that merges
-                                     the KV splits of a (sequence, KV head) did not see a
-                                     sibling's partial result within two seconds (a workspace
-                                     shared by overlapping calls, or one that held stale ready
-                                     tags); its output rows were filled with NaN               */
 };
 int pe_device_diagnostics(unsigned int* flags_out, int reset);
 
@@ -147,12 +142,7 @@ int pe_reshape_and_cache(const void* key, const void* value, void* key_cache,
  *   alibi_slopes   optional device float[num_heads]
  *   max_seq_len    upper bound of seq_lens (sizes the split-KV partition count only)
  *   workspace      device scratch of at least pe_paged_decode_workspace_bytes(...) bytes;
- *                  may be NULL when that function returns 0.  It must be ZERO-FILLED before its
- *                  first use with this library and written by nobody else between calls: the
- *                  partial results of the KV splits are merged inside the attention launch (no
- *                  second launch), each 64-bit word of a partial carrying a "ready" tag that the
- *                  merging workgroup clears again once it has read the word, so a call leaves
- *                  the workspace as tag-free as it found it.  Calls that overlap on one
+ *                  may be NULL when that function returns 0.  Calls that overlap on one
  *                  workspace (different streams) race on it.
  * softmax follows the CUDA kernel: p = exp(l - max) / (sum + 1e-6) (:342).
  * Kernel choice: 16-bit dtypes with block_size 16 (head_size 64/128/256) or block_size 8/32
@@ -250,9 +240,8 @@ int pe_decode_step_rope(void* out, const void* query, const void* new_key, const
  * GPU the library runs on until the process ends.  The call allocates and frees nothing; a call
  * whose partials would not fit returns PE_ERR_WORKSPACE and launches nothing.  All calls on one
  * GPU share that GPU's array: calls that overlap on one GPU (different streams or threads) race
- * on it and must be serialised by the caller.  The array starts zero-filled (static device
- * storage) and every call clears the ready tags it set, so nothing has to be cleared between
- * calls.  The array used is that of the device `stream` belongs to (of the current device for
+ * on it and must be serialised by the caller.  Every byte of the array that a call reads was
+ * written by the same call, so nothing has to be cleared between calls.  The array used is that of the device `stream` belongs to (of the current device for
  * the NULL stream), which must be the current device.  pe_paged_decode_noalloc_max_bytes() also
  * resolves the array's address on the current device: call it once per device at set-up, outside
  * any stream capture, so that the first pe_paged_decode_noalloc on that device may run under

@@ -28,9 +28,9 @@ def test_library_exports_every_declared_symbol():
     assert lib.pe_version() >= 101
     # workspace helpers are pure host functions
     # sized for the largest split count a launch may use: one split per 4 block pairs of 32 tokens,
-    # at most 64; a partial is m, l and head_size outputs per head, one 64-bit word each (value + tag)
-    assert lib.pe_paged_decode_workspace_bytes(64, 32, 8, 128, 16, 776) == 6 * 64 * 32 * (128 + 2) * 8
-    assert lib.pe_paged_decode_workspace_bytes(64, 32, 8, 128, 16, 100000) == 64 * 64 * 32 * (128 + 2) * 8
+    # at most 64
+    assert lib.pe_paged_decode_workspace_bytes(64, 32, 8, 128, 16, 776) == 6 * 64 * 32 * (128 + 2) * 4
+    assert lib.pe_paged_decode_workspace_bytes(64, 32, 8, 128, 16, 100000) == 64 * 64 * 32 * (128 + 2) * 4
     assert lib.pe_paged_decode_workspace_bytes(64, 32, 8, 128, 16, 220) == 0      # 7 pairs: one split
     prev = 0
     for n in range(1, 40000, 97):       # never shrinks as the maximum length grows

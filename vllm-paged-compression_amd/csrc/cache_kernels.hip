@@ -253,7 +253,7 @@ __global__ void copy_blocks_kernel(void* const* __restrict__ key_ptrs,
 extern "C" {
 
 const char* pe_last_error(void) { return pe::g_last_error; }
-int pe_version(void) { return 105; }  // 105: pe_reload_env, in-launch split merge, all-reduce status word
+int pe_version(void) { return 105; }  // 105: pe_reload_env, all-reduce status word + self-check
 void pe_reload_env(void) { pe::g_env_generation.fetch_add(1, std::memory_order_relaxed); }
 
 int pe_device_diagnostics(unsigned int* flags_out, int reset) {

@@ -67,29 +67,8 @@ struct RopeArgs {
   int64_t max_position;
 };
 
-// Partial results of one split: [split][seq][head] -> m, l, then O[D]; one 64-bit word each
-// (f32 value in the low half, the ready tag of the in-launch merge in the high half)
+// Partial results of one split: [split][seq][head] -> m, l, then O[D] (all f32)
 __host__ __device__ inline int64_t ws_stride(int head_size) { return head_size + 2; }
-constexpr int64_t WS_WORD = 8;
-
-// Split-KV partials carry their own "ready" signal when the splits are merged inside the launch:
-// a word is {f32 value, MERGE_TAG}, written and read as one 64-bit device-scope atomic (relaxed:
-// the value and its tag travel together, so no fence and no separate flag round trip is needed),
-// and cleared by the merging workgroup once read.  The workspace must therefore hold no
-// MERGE_TAG words before its first use (zero-filled by the caller) - see include/paged_evict.h.
-constexpr uint32_t MERGE_TAG = 0x5ea1ed01u;
-constexpr unsigned long long MERGE_TIMEOUT_TICKS = 200000000ull;  // 2 s of the 100 MHz clock
-__device__ __forceinline__ void ws_publish(uint64_t* p, float v) {
-  __hip_atomic_store(p, ((uint64_t)MERGE_TAG << 32) | (uint64_t)__float_as_uint(v), __ATOMIC_RELAXED,
-                     __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ uint64_t ws_peek(const uint64_t* p) {
-  return __hip_atomic_load(const_cast<uint64_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ bool ws_tagged(uint64_t v) { return (uint32_t)(v >> 32) == MERGE_TAG; }
-__device__ __forceinline__ void ws_clear(uint64_t* p) {
-  __hip_atomic_store(p, (uint64_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 // WAVES: waves per workgroup.  4 (two workgroups per CU) is the throughput shape; 8 and 16 are
 // the latency shapes for launches with few (sequence, KV head) pairs: the block pairs of a
@@ -121,7 +100,7 @@ void paged_decode_mfma_kernel(
     const T* __restrict__ new_value, const int64_t* __restrict__ new_slots, int64_t new_k_stride,
     int64_t new_v_stride, int64_t num_slots, T* key_cache_w, T* value_cache_w,
     const int64_t* __restrict__ rope_positions, const T* __restrict__ rope_cos_sin, int rot_dim,
-    int rope_neox, int64_t rope_max_position, int merge_in_launch) {
+    int rope_neox, int64_t rope_max_position) {
   // key_cache_w / value_cache_w: the same caches through non-restrict pointers, used only by
   // the fused KV write (the written slot is never loaded by this launch).
   using TR = Traits<T>;
@@ -526,17 +505,8 @@ void paged_decode_mfma_kernel(
     }
   }
   __syncthreads();
-  // Every thread owns one (head, d) element per round; the rounds are workgroup-uniform because
-  // the merging workgroup synchronises inside them.
-  constexpr int NT = WAVES * 64;
-  const int total = gqa * HEAD_SIZE;
-  const bool merger = merge_in_launch != 0 && num_splits > 1 && split == num_splits - 1;
-  uint64_t* ws64 = reinterpret_cast<uint64_t*>(ws);
-  const int64_t wstride = ws_stride(HEAD_SIZE);
-  for (int base = 0; base < total; base += NT) {
-    const int i = base + (int)threadIdx.x;
-    const bool active = i < total;
-    const int h = active ? i / HEAD_SIZE : 0, d = active ? i % HEAD_SIZE : 0;
+  for (int i = threadIdx.x; i < gqa * HEAD_SIZE; i += WAVES * 64) {
+    const int h = i / HEAD_SIZE, d = i % HEAD_SIZE;
     float m_tot = sm_m[h];
 #pragma unroll
     for (int w = 1; w < WAVES; ++w) m_tot = fmaxf(m_tot, sm_m[w * 16 + h]);
@@ -548,128 +518,70 @@ void paged_decode_mfma_kernel(
       l += f * sm_l[w * 16 + h];
     }
     const int head = kvh * gqa + h;
-    T* dst = out + ((int64_t)seq * num_heads + head) * HEAD_SIZE + d;
     if (num_splits == 1) {
-      if (active) *dst = (T)(o * (1.f / (l + 1e-6f)));
-      continue;
-    }
-    if (!merger) {
-      // partial of this split: 64-bit words {f32 value, tag}.  With the merge inside the launch
-      // the words are device-scope atomic stores that carry MERGE_TAG: the reader needs no
-      // other signal than the word itself.
-      if (active) {
-        uint64_t* w = ws64 + (((int64_t)split * num_seqs + seq) * num_heads + head) * wstride;
-        if (merge_in_launch) {
-          if (d == 0) {
-            ws_publish(w, m_tot);
-            ws_publish(w + 1, l);
-          }
-          ws_publish(w + 2 + d, o);
-        } else {
-          if (d == 0) {
-            w[0] = (uint64_t)__float_as_uint(m_tot);
-            w[1] = (uint64_t)__float_as_uint(l);
-          }
-          w[2 + d] = (uint64_t)__float_as_uint(o);
-        }
+      out[((int64_t)seq * num_heads + head) * HEAD_SIZE + d] = (T)(o * (1.f / (l + 1e-6f)));
+    } else {
+      float* w = ws + (((int64_t)split * num_seqs + seq) * num_heads + head) * ws_stride(HEAD_SIZE);
+      if (d == 0) {
+        w[0] = m_tot;
+        w[1] = l;
       }
-      continue;
-    }
-    // The last split of a (sequence, KV head) merges: it was dispatched behind its siblings
-    // (blockIdx.x runs fastest), so all of them are resident or done and none of them ever
-    // waits - polling here cannot deadlock.  A thread polls exactly the words it needs.
-    float M = m_tot, acc_o = o, acc_l = l;
-    bool bad = false;
-    uint64_t* w0 = ws64 + ((int64_t)seq * num_heads + head) * wstride;
-    const int64_t split_stride = (int64_t)num_seqs * num_heads * wstride;
-    const int n_sib = num_splits - 1;
-    if (active) {
-      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-      for (int s0 = 0; s0 < n_sib && !bad; s0 += 4) {
-        uint64_t vm[4], vl[4], vo[4];
-        while (true) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const uint64_t* w = w0 + (int64_t)min(s0 + k, n_sib - 1) * split_stride;
-            vm[k] = ws_peek(w);
-            vl[k] = ws_peek(w + 1);
-            vo[k] = ws_peek(w + 2 + d);
-          }
-          bool ready = true;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) ready = ready && ws_tagged(vm[k]) && ws_tagged(vl[k]) && ws_tagged(vo[k]);
-          if (ready) break;
-          if (__builtin_amdgcn_s_memrealtime() - t0 > MERGE_TIMEOUT_TICKS) {
-            bad = true;
-            break;
-          }
-          __builtin_amdgcn_s_sleep(1);
-        }
-        if (bad) break;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          if (s0 + k < n_sib) {
-            const float ms = __uint_as_float((uint32_t)vm[k]);
-            const float m_new = fmaxf(M, ms);
-            const float fa = __expf(M - m_new), fb = __expf(ms - m_new);
-            acc_o = acc_o * fa + __uint_as_float((uint32_t)vo[k]) * fb;
-            acc_l = acc_l * fa + __uint_as_float((uint32_t)vl[k]) * fb;
-            M = m_new;
-          }
-        }
-      }
-    }
-    __syncthreads();  // every thread of the round has read its words: clear them for the next launch
-    if (active) {
-      if (!bad) {
-        for (int s = 0; s < n_sib; ++s) {
-          uint64_t* w = w0 + (int64_t)s * split_stride;
-          ws_clear(w + 2 + d);
-          if (d == 0) {
-            ws_clear(w);
-            ws_clear(w + 1);
-          }
-        }
-        *dst = (T)(acc_o * (1.f / (acc_l + 1e-6f)));
-      } else {
-        // a sibling never delivered (a bug or a dying launch): poison instead of a partial sum
-        *dst = (T)__uint_as_float(0x7fc00000u);
-        atomicOr(&decode_diag_word, (unsigned)PE_DIAG_DECODE_MERGE_TIMEOUT);
-      }
+      w[2 + d] = o;
     }
   }
 }
 
-// Merge of the split partials in a launch of its own (PE_DECODE_MERGE=launch; the default merges
-// inside the attention launch): grid (num_heads, num_seqs), one thread per d.  Eight splits'
-// words are requested before any is used.
-template <typename T>
-__global__ void paged_decode_merge_kernel(T* __restrict__ out, const uint64_t* __restrict__ ws,
+// merge of the split partials: grid (num_heads, num_seqs), one thread per d.  All partials of
+// a thread are requested before any is used (one memory round trip instead of one per pass).
+template <typename T, int MAX_SPLITS>
+__global__ void paged_decode_merge_kernel(T* __restrict__ out, const float* __restrict__ ws,
                                           int num_heads, int head_size, int num_splits) {
   const int head = blockIdx.x, seq = blockIdx.y, num_seqs = gridDim.y;
   const int64_t stride = ws_stride(head_size);
   const int64_t split_stride = (int64_t)num_seqs * num_heads * stride;
-  const uint64_t* base = ws + ((int64_t)seq * num_heads + head) * stride;
+  const float* base = ws + ((int64_t)seq * num_heads + head) * stride;
   for (int d = threadIdx.x; d < head_size; d += blockDim.x) {
-    float M = NEG_BIG, acc = 0.f, lsum = 0.f;
-    for (int s0 = 0; s0 < num_splits; s0 += 8) {
-      float m[8], l[8], o[8];
+    float m[MAX_SPLITS], l[MAX_SPLITS], o[MAX_SPLITS];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const bool on = s0 + k < num_splits;
-        const uint64_t* w = base + (on ? s0 + k : 0) * split_stride;
-        m[k] = on ? __uint_as_float((uint32_t)w[0]) : NEG_BIG;
-        l[k] = on ? __uint_as_float((uint32_t)w[1]) : 0.f;
-        o[k] = on ? __uint_as_float((uint32_t)w[2 + d]) : 0.f;
-      }
+    for (int s = 0; s < MAX_SPLITS; ++s) {
+      const bool on = s < num_splits;
+      const float* w = base + (on ? s : 0) * split_stride;
+      m[s] = on ? w[0] : NEG_BIG;
+      l[s] = on ? w[1] : 0.f;
+      o[s] = on ? w[2 + d] : 0.f;
+    }
+    float m_tot = NEG_BIG;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const float m_new = fmaxf(M, m[k]);
-        const float fa = __expf(M - m_new), fb = __expf(m[k] - m_new);
-        acc = acc * fa + o[k] * fb;
-        lsum = lsum * fa + l[k] * fb;
-        M = m_new;
-      }
+    for (int s = 0; s < MAX_SPLITS; ++s) m_tot = fmaxf(m_tot, m[s]);
+    float acc = 0.f, lsum = 0.f;
+#pragma unroll
+    for (int s = 0; s < MAX_SPLITS; ++s) {
+      const float f = __expf(m[s] - m_tot);
+      acc += f * o[s];
+      lsum += f * l[s];
+    }
+    out[((int64_t)seq * num_heads + head) * head_size + d] = (T)(acc * (1.f / (lsum + 1e-6f)));
+  }
+}
+
+// More than 16 splits (only a forced split count gets there): the same merge as a plain loop -
+// the maximum first, then the weighted sums in split order.
+template <typename T>
+__global__ void paged_decode_merge_loop_kernel(T* __restrict__ out, const float* __restrict__ ws,
+                                               int num_heads, int head_size, int num_splits) {
+  const int head = blockIdx.x, seq = blockIdx.y, num_seqs = gridDim.y;
+  const int64_t stride = ws_stride(head_size);
+  const int64_t split_stride = (int64_t)num_seqs * num_heads * stride;
+  const float* base = ws + ((int64_t)seq * num_heads + head) * stride;
+  for (int d = threadIdx.x; d < head_size; d += blockDim.x) {
+    float m_tot = NEG_BIG;
+    for (int s = 0; s < num_splits; ++s) m_tot = fmaxf(m_tot, base[s * split_stride]);
+    float acc = 0.f, lsum = 0.f;
+    for (int s = 0; s < num_splits; ++s) {
+      const float* w = base + s * split_stride;
+      const float f = __expf(w[0] - m_tot);
+      acc += f * w[2 + d];
+      lsum += f * w[1];
     }
     out[((int64_t)seq * num_heads + head) * head_size + d] = (T)(acc * (1.f / (lsum + 1e-6f)));
   }
@@ -867,7 +779,7 @@ int64_t pe_paged_decode_workspace_bytes(int num_seqs, int num_heads, int num_kv_
   // sized for the largest split count choose_splits can pick, so a caller may allocate once
   const int max_splits = pe::split_cap(max_seq_len);
   if (max_splits <= 1) return 0;
-  return (int64_t)max_splits * num_seqs * num_heads * pe::ws_stride(head_size) * pe::WS_WORD;
+  return (int64_t)max_splits * num_seqs * num_heads * pe::ws_stride(head_size) * 4;
 }
 
 static int decode_impl(void* out, const void* query, const void* key_cache, const void* value_cache,
@@ -904,13 +816,9 @@ static int decode_impl(void* out, const void* query, const void* key_cache, cons
     // the rotating form, the 8-/32-token-block forms and head size 256 (whose 16-wave form would
     // spill) are built for 4 and 8 waves
     if ((rope != nullptr || block_size != 16 || head_size > 128) && waves > 8) waves = 8;
-    // PE_DECODE_MERGE=launch: the split partials are merged by a second launch instead of by the
-    // last split's workgroup (A/B measurements, differential tests)
-    static EnvInt merge_launch_var("PE_DECODE_MERGE_LAUNCH", 0);
-    const int merge_in_launch = merge_launch_var.get() ? 0 : 1;
     float* ws = static_cast<float*>(workspace);
     if (splits > 1) {
-      const int64_t need = (int64_t)splits * num_seqs * num_heads * ws_stride(head_size) * WS_WORD;
+      const int64_t need = (int64_t)splits * num_seqs * num_heads * ws_stride(head_size) * 4;
       PE_REQUIRE(workspace && workspace_bytes >= need, PE_ERR_WORKSPACE,
                  "paged_decode needs %lld workspace bytes, got %lld", (long long)need,
                  (long long)workspace_bytes);
@@ -928,8 +836,7 @@ static int decode_impl(void* out, const void* query, const void* key_cache, cons
                      splits, (const T*)new_key, (const T*)new_value, new_slots, new_k_stride,       \
                      new_v_stride, num_slots, (T*)key_cache, (T*)value_cache,                      \
                      R ? rope->positions : nullptr, R ? (const T*)rope->cos_sin : nullptr,         \
-                     R ? rope->rot_dim : 0, R ? rope->is_neox : 0, R ? rope->max_position : 0,     \
-                     merge_in_launch)
+                     R ? rope->rot_dim : 0, R ? rope->is_neox : 0, R ? rope->max_position : 0)
 #define PE_LAUNCH_DEC_W(T, HS, W) PE_LAUNCH_DEC_WR(T, HS, W, false)
 #define PE_LAUNCH_DEC_B(T, HS, W, B)                                                               \
   if (lds > 64 * 1024)                                                                             \
@@ -942,7 +849,7 @@ static int decode_impl(void* out, const void* query, const void* key_cache, cons
                      max_num_blocks_per_seq, q_stride, kv_block_stride, kv_head_stride, scale,     \
                      splits, (const T*)new_key, (const T*)new_value, new_slots, new_k_stride,       \
                      new_v_stride, num_slots, (T*)key_cache, (T*)value_cache, nullptr, nullptr, 0, \
-                     0, 0, merge_in_launch)
+                     0, 0)
 #define PE_LAUNCH_DEC(T, HS)                               \
   do {                                                     \
     if (block_size != 16) {                                \
@@ -989,12 +896,21 @@ static int decode_impl(void* out, const void* query, const void* key_cache, cons
 #undef PE_LAUNCH_DEC_W
 #undef PE_LAUNCH_DEC_WR
     if (int rc = check_launch("paged_decode")) return rc;
-    if (splits > 1 && !merge_in_launch) {
-      PE_DISPATCH_16(dtype, T,
-                     hipLaunchKernelGGL((paged_decode_merge_kernel<T>),
-                                        dim3((unsigned)num_heads, (unsigned)num_seqs),
-                                        dim3(head_size <= 64 ? 64 : 128), 0, st, (T*)out,
-                                        (const uint64_t*)ws, num_heads, head_size, splits));
+    if (splits > 1) {
+#define PE_LAUNCH_MERGE(T, MS)                                                                   \
+  hipLaunchKernelGGL((paged_decode_merge_kernel<T, MS>), dim3((unsigned)num_heads, (unsigned)num_seqs), \
+                     dim3(head_size <= 64 ? 64 : 128), 0, st, (T*)out, ws, num_heads, head_size, splits)
+      PE_DISPATCH_16(dtype, T, {
+        if (splits <= 4) PE_LAUNCH_MERGE(T, 4);
+        else if (splits <= 8) PE_LAUNCH_MERGE(T, 8);
+        else if (splits <= 16) PE_LAUNCH_MERGE(T, 16);
+        else
+          hipLaunchKernelGGL((paged_decode_merge_loop_kernel<T>),
+                             dim3((unsigned)num_heads, (unsigned)num_seqs),
+                             dim3(head_size <= 64 ? 64 : 128), 0, st, (T*)out, ws, num_heads, head_size,
+                             splits);
+      });
+#undef PE_LAUNCH_MERGE
       if (int rc = check_launch("paged_decode_merge")) return rc;
     }
     return PE_OK;

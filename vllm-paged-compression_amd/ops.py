@@ -63,16 +63,13 @@ _workspaces: Dict[Tuple[str, int], torch.Tensor] = {}
 
 
 def _workspace(dev: torch.device, nbytes: int, tag: str = "decode") -> Optional[torch.Tensor]:
-    """Per-device scratch buffer, grown on demand (allocated by torch, outside the C call).
-    Zero-filled when it is created: the decode kernels merge their KV splits inside the launch
-    and recognise a finished partial result by a tag in the workspace words, which every launch
-    clears again behind itself - the buffer must simply never start out with such tags."""
+    """Per-device scratch buffer, grown on demand (allocated by torch, outside the C call)."""
     if nbytes <= 0:
         return None
     key = (tag, dev.index if dev.index is not None else torch.cuda.current_device())
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
-        ws = torch.zeros(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
         _workspaces[key] = ws
     return ws
 
@@ -92,7 +89,6 @@ def _check_kv_cache_args(kv_cache_dtype: str, k_scale: float, v_scale: float) ->
 
 
 DIAG_DECODE_LEN_CLAMPED, DIAG_SCORE_ROW_FULL, DIAG_TABLE_STATE_MISMATCH = 1, 2, 4
-DIAG_DECODE_MERGE_TIMEOUT = 8
 
 
 def device_diagnostics(reset: bool = True) -> int:
@@ -118,9 +114,6 @@ def check_device_diagnostics() -> None:
             what.append("a block score was dropped because the sequence's score row was full")
         if flags & DIAG_TABLE_STATE_MISMATCH:
             what.append("device-resident block tables disagree with the host's counters")
-        if flags & DIAG_DECODE_MERGE_TIMEOUT:
-            what.append("a decode launch gave up waiting for a KV split's partial result "
-                        "(NaN written; is the workspace shared by overlapping launches?)")
         raise RuntimeError("paged_evict device diagnostics: " + "; ".join(what))
 
 
