@@ -110,12 +110,18 @@ def parse():
                     help="vectorised scheduler with the block tables kept on the host and uploaded "
                          "every decode step (default: tables resident on the GPU, one int per "
                          "sequence uploaded per step)")
-    ap.add_argument("--graph-decode", action="store_true",
-                    help="replay the attention launches of a decode step (all layers) from a HIP graph "
-                         "captured on the first step that evicts nothing; steps with an eviction "
-                         "decision run eagerly.  Needs the resident tables (the captured launches "
-                         "read the step's metadata from the same device buffers every step).  Pays "
-                         "when the step is launch-bound (few sequences)")
+    ap.add_argument("--graph-decode", dest="graph_decode", action="store_true", default=None,
+                    help="replay the launches of a decode step (all layers) from HIP graphs: one for the "
+                         "steps that evict nothing, one (budget prune type, streamingLLM / global / "
+                         "local, single GPU) for the steps with an eviction decision, whose victims "
+                         "are read back after the replay; other eviction steps run eagerly.  Needs the "
+                         "resident tables (the captured launches read the step's metadata from the same "
+                         "device buffers every step).  Default: on when a decode launch moves less than "
+                         "150 MB, i.e. when the step would be bound by the host's launch rate (few "
+                         "sequences, or one rank's heads of a tensor-parallel job); the headline "
+                         "workload (204 MB per launch) runs eagerly")
+    ap.add_argument("--no-graph-decode", dest="graph_decode", action="store_false",
+                    help="launch every decode step eagerly")
     ap.add_argument("--rope", choices=["off", "separate", "fused"], default="off",
                     help="also run the rotary embedding that precedes attention in the model "
                          "(llama.py:202-203) on every layer's query/key rows: separate = its own "
@@ -211,7 +217,7 @@ class Workload:
         self.o_partial_p = self.o_partial_d = None
         if self.allreduce:
             from vllm_paged_compression_amd import parallel
-            if parallel._one_shot.get(id(tp_group)) is None:
+            if id(tp_group) not in parallel._one_shot and os.environ.get("PE_AR_DISABLE", "0") in ("", "0"):
                 # decode-sized partials (<= 8 MiB) go through the exchange over the peer-mapped
                 # buffers (one stage, or two from 256-512 KiB), larger ones through the group's
                 # backend (RCCL)
@@ -232,6 +238,17 @@ class Workload:
         self.timed_prefill = []  # (start_event, end_event, flops) per prefill-attention launch
         self.timing_on = False
         self.kv_blocks_peak = 0
+        # launch-bound decode steps are replayed from HIP graphs (see --graph-decode); the graphs
+        # and the device-resident table state they read live as long as the workload, so a graph
+        # captured in one generation serves the next ones too
+        self._dev_state = None
+        self._graphs = {}
+        self.graph_replays = 0
+        self.graph_evict_replays = 0
+        per_launch = B * (2 * max_kv * self.Hkv * self.D * 2)      # K and V bytes a decode launch reads
+        self.use_graph = (a.graph_decode if a.graph_decode is not None else per_launch < 150e6) \
+            and not a.host_tables and not a.reference_head_compat and not a.per_request_scheduler \
+            and not self.allreduce and a.rope == "off"
 
     # ---- metadata -------------------------------------------------------------------------
     def _builder(self, inter):
@@ -279,14 +296,19 @@ class Workload:
             self.timed_prefill += [(s, e, prefill_flops) for s, e in sink]
 
     def _capture_decode(self, meta, max_len: int):
-        """The attention launches of one decode step, all layers, captured into a HIP graph.  The
-        step's metadata tensors are the scheduler's resident device buffers, so later steps
-        replay the same launches on new contents; the length that sizes the KV splits is fixed
-        at the generation's maximum."""
+        """The launches of one decode step, all layers, captured into a HIP graph.  The step's
+        metadata tensors are the scheduler's resident device buffers, so later steps replay the
+        same launches on new contents; the length that sizes the KV splits is fixed at the
+        generation's maximum.  On a step with an eviction decision the first layer's decision
+        launch (victim choice + in-place table compaction, which tests every sequence's trigger
+        on the device) is part of the graph; returns (graph, device tensor of the victims)."""
         meta.max_decode_seq_len = max_len
         dm = meta.decode_metadata
         if dm is not None and dm is not meta:
             dm.max_decode_seq_len = max_len
+        if self.cfg is not None and dm is not None and dm.seq_kv_lens:
+            # the impl sizes the splits by the longest physical length: pin it for all replays
+            dm.seq_kv_lens = [min(max_len, self.blocks_per_seq * self.bs)] * len(dm.seq_kv_lens)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         graph = torch.cuda.CUDAGraph()
@@ -295,7 +317,10 @@ class Workload:
                 for li, impl in enumerate(self.impls):
                     impl.forward(self.qd, self.kd, self.vd, self.kv[li], meta)
         torch.cuda.current_stream().wait_stream(side)
-        return graph
+        dec = meta._pe_step.get("decode") or {}
+        # (the third entry keeps alive what the captured decision launch reads besides the
+        # resident table state: the score-row indices of the batch)
+        return graph, dec.get("rmv_dev"), getattr(self._dev_state, "score_rows", None)
 
     def _replay_decode(self, graph, decode_bytes: int) -> None:
         if self.timing_on:
@@ -307,6 +332,7 @@ class Workload:
             self.timed.append((s_ev, e_ev, decode_bytes, len(self.impls)))
         else:
             graph.replay()
+        self.graph_replays += 1
 
     def _prefill_flops(self, n_req: int) -> float:
         """4 * Hq * D * sum_i min(i+1, L_kv) per request: both contractions, causal, the kv length
@@ -333,6 +359,7 @@ class Workload:
         if self.a.per_request_scheduler:
             return self._generate_per_request()
         import numpy as np
+        from vllm_paged_compression_amd import staging
         from vllm_paged_compression_amd.batch_scheduler import BatchEvictionScheduler
         from vllm_paged_compression_amd.page_evict_kv_util import budget_decode_trigger
         a, bs = self.a, self.bs
@@ -340,7 +367,8 @@ class Workload:
         sched = BatchEvictionScheduler(bs, self.num_blocks, self.cfg, max_seqs=B,
                                        max_blocks_per_seq=self.blocks_per_seq_full + 2,
                                        device=None if (a.host_tables or a.reference_head_compat)
-                                       else self.dev)
+                                       else self.dev, device_state=self._dev_state)
+        self._dev_state = sched.device_state
         rids = [f"req{i}" for i in range(B)]
         for i, r in enumerate(rids):
             sched.add_request(r, i, L0)
@@ -361,8 +389,14 @@ class Workload:
         # decode: one vectorised scheduler step + one metadata build per step
         L = L0
         es = 2
-        use_graph = a.graph_decode and not a.host_tables and not self.allreduce and a.rope == "off"
-        graph, warmed = None, False
+        use_graph = self.use_graph
+        # an eviction step can be replayed too when its decision needs nothing from the host:
+        # budget type, victims chosen on the device (or fixed), one GPU (under tensor parallelism
+        # the scores take an all-reduce, left eager)
+        evict_graph = (use_graph and self.cfg is not None and not self.percentage and self.tp_group is None
+                       and self.cfg.evict_method in ("streamingLLM", "global", "local"))
+        warmed = "plain" in self._graphs
+        warmed_ev = "evict" in self._graphs
         for it in range(a.output_len):
             batch = sched.schedule_decode(rids)
             L += 1
@@ -385,13 +419,26 @@ class Workload:
             if self.cos_sin is not None:
                 self.pos_d.fill_(L - 1)      # position of the step's token
             if use_graph and plain and warmed:
-                if graph is None:
-                    graph = self._capture_decode(meta, L0 + a.output_len)
-                self._replay_decode(graph, nbytes)
+                if "plain" not in self._graphs:
+                    self._graphs["plain"] = self._capture_decode(meta, L0 + a.output_len)
+                self._replay_decode(self._graphs["plain"][0], nbytes)
+            elif evict_graph and not plain and warmed_ev:
+                if "evict" not in self._graphs:
+                    self._graphs["evict"] = self._capture_decode(meta, L0 + a.output_len)
+                graph_ev, rmv_dev = self._graphs["evict"][:2]
+                graph_ev.replay()
+                self.graph_replays += 1
+                self.graph_evict_replays += 1
+                # the victims feed the host's free list: one small read-back per eviction step
+                rmv = staging.AsyncReadback(rmv_dev[:B]).tolist()
+                sched.commit({i: (rids[i], r) for i, r in enumerate(rmv) if r >= 0})
             else:
                 self._layers(self.qd, self.kd, self.vd, meta, self.o_partial_d, decode_bytes=nbytes,
                              positions=None if self.cos_sin is None else self.pos_d)
-                warmed = True
+                if plain:
+                    warmed = True
+                else:
+                    warmed_ev = True
                 if self.cfg is not None:
                     sched.commit(self.impls[0].get_rmv_block_idx())
             used = self.num_blocks - sched.get_num_free_gpu_blocks()
@@ -588,6 +635,19 @@ def spawn_ranks(n: int) -> int:
     return subprocess.call(cmd)
 
 
+def wl_comm_lost(dist, dev) -> bool:
+    """Whether the peer-buffer exchange of any rank gave up a wait (its outputs were NaN): such a
+    run must not pass for a measurement."""
+    from vllm_paged_compression_amd import parallel
+    comm = parallel._one_shot.get(id(dist.group.WORLD))
+    lost = 0
+    if comm is not None and comm._own is not None:
+        lost = comm.timeouts()
+    t = torch.tensor([lost], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(t.item()) > 0
+
+
 def timed_generations(wl, n, sync, dist, dev, world):
     t0 = time.perf_counter()
     for _ in range(n):
@@ -722,8 +782,8 @@ def main():
             "devices": devices,
             "oproj_allreduce": bool(wl.allreduce), "rope": a.rope,
             "reference_head_compat": bool(a.reference_head_compat),
-            "graph_decode": bool(a.graph_decode and not a.host_tables and not wl.allreduce
-                                 and a.rope == "off"), **kv},
+            "graph_decode": bool(wl.use_graph), "graph_replays": wl.graph_replays,
+            "graph_evict_replays": wl.graph_evict_replays, **kv},
     }
     if os.environ.get("PE_BENCH_KV_CHECKSUM"):
         # bit-level sum of every layer's KV cache after the last generation (A/B of launch modes)
@@ -749,6 +809,46 @@ def main():
             "ms_per_step": round(dt3 / n3 * 1e3, 3)}
         del wl3
         torch.cuda.empty_cache()
+    exit_code = 0
+    if tp and not a.oproj_allreduce:
+        # the exchange that follows attention in the model: the same weak-scaling job with the
+        # all-reduce of a [tokens, hidden] o_proj partial after every layer (the GEMM itself is
+        # outside the path and not run).  Reported beside the attention-only value, never as it.
+        import copy
+        from vllm_paged_compression_amd import parallel
+        a4 = copy.copy(a)
+        a4.oproj_allreduce = True
+        leg = {"path_decode": None, "path_prefill": None, "ar_timeouts": None}
+        try:
+            wl4 = Workload(a4, dev, world, rank, dist.group.WORLD)
+            comm = parallel._one_shot.get(id(dist.group.WORLD))
+            es4 = 2
+            msg_d = a4.num_prompts * wl4.hidden * es4
+            msg_p = a4.prefill_batch * a4.input_len * wl4.hidden * es4
+            leg.update(decode_message_bytes=msg_d, prefill_message_bytes=msg_p,
+                       path_decode=comm.path(msg_d) if comm is not None else "backend",
+                       path_prefill=comm.path(msg_p) if comm is not None else "backend",
+                       peer_buffers=("off (PE_AR_DISABLE)" if comm is None else
+                                     "on" if comm.enabled else f"off: {comm.disabled_reason}"))
+            wl4.generate()
+            sync()
+            n4 = max(1, min(a.steps, 2))
+            dt4 = timed_generations(wl4, n4, sync, dist, dev, world)
+            lost = 0
+            if comm is not None and comm._own is not None:
+                lost = comm.timeouts()
+            t = torch.tensor([lost], dtype=torch.int64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            leg.update(value=round(a4.num_prompts * a.output_len * n4 / dt4, 2), steps=n4,
+                       ms_per_step=round(dt4 / n4 * 1e3, 3), ar_timeouts=int(t.item()))
+            if leg["ar_timeouts"] > 0:
+                exit_code = 3
+            del wl4
+            torch.cuda.empty_cache()
+        except Exception as e:          # reported on the line; the attention-only value stands
+            leg["error"] = repr(e)[:300]
+            exit_code = 3
+        out["config"]["with_oproj_allreduce"] = leg
     if a.alt_evict > 0 and a.cache_budget == 0 and a.cache_prune_type == "budget" \
             and abs(a.alt_evict - a.evict) > 1e-9:
         # the same job at the metric's other eviction fraction (outside the timed region above)
@@ -776,10 +876,21 @@ def main():
             out["cpu_baseline"] = cpu_baseline(a, main_budget)
         except Exception as e:  # the baseline never decides the run
             out["cpu_baseline"] = {"value": None, "error": repr(e)}
+    if world > 1 and wl_comm_lost(dist, dev):
+        exit_code = 3
+        out["config"]["ar_timeouts_main"] = True
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
+        from vllm_paged_compression_amd import parallel
+        try:
+            parallel.disable_one_shot_all_reduce(dist.group.WORLD)
+        except parallel.AllReduceError as e:
+            print(f"[bench] {e}", file=sys.stderr, flush=True)
+            exit_code = 3
         dist.destroy_process_group()
+    if exit_code:
+        raise SystemExit(exit_code)
 
 
 if __name__ == "__main__":

@@ -55,6 +55,13 @@ def test_bench_gpus_2_starts_two_ranks():
     assert len(c["devices"]) == 2
     assert "8 requests" in c["workload"]          # weak scaling: 2 x 4 requests over half the heads each
     assert c["tp_strong"]["requests"] == 4 and c["tp_strong"]["value"] > 0
+    # the o_proj exchange leg: same job with an all-reduce per layer through the peer-mapped
+    # buffers, reported beside the attention-only value; no wait may have given up
+    leg = c["with_oproj_allreduce"]
+    assert "error" not in leg, leg
+    assert leg["value"] > 0 and leg["ar_timeouts"] == 0 and leg["peer_buffers"] == "on"
+    assert leg["path_decode"] == "oneshot" and leg["decode_message_bytes"] == 8 * 4096 * 2
+    assert c["graph_decode"] is True and c["graph_replays"] > 0        # launch-bound: replayed by default
     # WORLD_SIZE that contradicts --gpus
     env1 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     bad = subprocess.run(cmd, capture_output=True, text=True, timeout=120, cwd=ROOT, env=env1)
@@ -87,20 +94,26 @@ def test_bench_presets_select_the_baseline_configs():
 @pytest.mark.parametrize("extra", [["--evict", "0"], [], ["--decode-evict-method", "streamingLLM"],
                                    ["--cache-prune-type", "percentage", "--evict-freq", "2"]])
 def test_bench_graph_decode_leaves_the_same_kv_cache(extra):
-    """--graph-decode replays the attention launches of the decode steps that evict nothing from
-    a HIP graph; the KV caches of all layers must end bit-identical to the eager run's, with the
-    same blocks held (evictions still happen, on their eager steps)."""
+    """--graph-decode replays the launches of the decode steps from HIP graphs - the steps that
+    evict nothing from one graph, the steps with an eviction decision of the budget prune type
+    from a second one whose victims are read back after the replay (the percentage type's
+    eviction steps stay eager); the KV caches of all layers must end bit-identical to the eager
+    run's, with the same blocks held.  Two generations: the second one replays graphs captured in
+    the first."""
     env = dict(os.environ, PE_BENCH_KV_CHECKSUM="1")
-    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0",
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "0",
             "--num-prompts", "4", "--prefill-batch", "4", "--input-len", "200", "--output-len", "70",
             "--layers", "3", "--no-cpu-baseline", "--alt-evict", "0", *extra]
     res = []
-    for mode in ([], ["--graph-decode"]):
+    for mode in (["--no-graph-decode"], ["--graph-decode"]):
         out = subprocess.run(base + mode, capture_output=True, text=True, timeout=280, cwd=ROOT, env=env)
         assert out.returncode == 0, out.stderr[-2000:]
         d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
         res.append(d["config"])
     assert res[0]["graph_decode"] is False and res[1]["graph_decode"] is True
+    assert res[0]["graph_replays"] == 0 and res[1]["graph_replays"] > 100
+    budget_type = "--evict" not in extra and "--cache-prune-type" not in extra
+    assert (res[1]["graph_evict_replays"] > 0) == budget_type
     assert res[0]["kv_checksum"] == res[1]["kv_checksum"] != 0
     assert res[0]["kv_gb_held_peak"] == res[1]["kv_gb_held_peak"]
 

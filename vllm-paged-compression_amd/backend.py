@@ -1128,10 +1128,11 @@ class PagedEvictImpl(_ImplBase):
         if method in ("streamingLLM", "streamingLLM-1"):
             need_zero = method == "streamingLLM-1" and bool((over_np & ~trig_np).any())
             if any_trig or need_zero:
-                _, _, zero = ops.evict_select_compact_inplace(
+                rmv, _, zero = ops.evict_select_compact_inplace(
                     st.tables, st.num_blocks, st.kv_lens, st.seq_lens, B, method, cfg.cache_budget, bs)
                 dec["zero_slots"] = zero
                 dec["host_rmv"] = {i: (req_ids[i], 1) for i, t in enumerate(trig) if t}
+                dec["rmv_dev"] = rmv
             return dec
         if not any_trig:
             return dec
@@ -1166,9 +1167,12 @@ class PagedEvictImpl(_ImplBase):
         rmv, _, _ = ops.evict_select_compact_inplace(
             st.tables, st.num_blocks, st.kv_lens, st.seq_lens, B, method, cfg.cache_budget, bs,
             cfg.topk_blocks, victim_override=override, **score_kw)
+        dec["rmv_dev"] = rmv     # the victims on the device (a caller replaying this step from a
+        #                          HIP graph reads them back itself after each replay)
         if dec["host_rmv"] is None:
             dec["rmv"] = rmv
-            dec["readback"] = staging.AsyncReadback(rmv)
+            if not torch.cuda.is_current_stream_capturing():
+                dec["readback"] = staging.AsyncReadback(rmv)
         return dec
 
     def _decode_decision_percentage(self, dm, L: np.ndarray, table_lens: np.ndarray,

@@ -104,14 +104,25 @@ class DeviceTableState:
 class BatchEvictionScheduler:
 
     def __init__(self, block_size: int, num_gpu_blocks: int, paged_evict_config=None,
-                 max_seqs: int = 256, max_blocks_per_seq: int = 512, device=None):
+                 max_seqs: int = 256, max_blocks_per_seq: int = 512, device=None,
+                 device_state: Optional[DeviceTableState] = None):
         """``device``: keep the running batch's tables on that GPU (``DeviceTableState``): decode
         steps then upload one int per sequence instead of the table matrix.  The arrays below
         remain the host's record of who owns which block (free-list accounting, the blocks to
-        release when a request finishes); they are brought up to date by ``commit``."""
+        release when a request finishes); they are brought up to date by ``commit``.
+        ``device_state``: a ``DeviceTableState`` of the same geometry to adopt instead of
+        allocating a new one."""
         self.device_state: Optional[DeviceTableState] = None
         if device is not None:
-            self.device_state = DeviceTableState(max_seqs, max_blocks_per_seq, device)
+            if device_state is not None and (device_state.capacity, device_state.max_blocks) == \
+                    (max_seqs, max_blocks_per_seq) and device_state.device == __import__("torch").device(device):
+                # adopt an existing state (launches captured into HIP graphs keep reading its
+                # buffers); whatever it holds belongs to nobody any more
+                device_state.key = device_state.score_rows_key = None
+                device_state.batch = 0
+                self.device_state = device_state
+            else:
+                self.device_state = DeviceTableState(max_seqs, max_blocks_per_seq, device)
         self.block_size = block_size
         self.paged_evict_config = paged_evict_config
         self.num_total_gpu_blocks = num_gpu_blocks
