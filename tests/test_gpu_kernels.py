@@ -160,7 +160,7 @@ DECODE_CASES = [
     (8, 1, 128, 16, torch.bfloat16, [3072, 100, 3088]),
     (64, 8, 128, 16, torch.bfloat16, [200, 40]),
     (16, 1, 256, 16, torch.bfloat16, [130, 33]),
-    (40, 40, 80, 16, torch.bfloat16, [77, 300]),      # generic path (head size)
+    (40, 40, 80, 16, torch.bfloat16, [77, 300]),      # head size 80: last k-step half empty
     (32, 8, 128, 32, torch.bfloat16, [100, 515]),     # 32-token blocks
     (8, 2, 64, 8, torch.float16, [9, 130]),           # 8-token blocks
     (32, 8, 128, 8, torch.bfloat16, [1, 7, 8, 9, 15, 16, 17, 31, 32, 33, 300, 777]),
@@ -179,7 +179,18 @@ DECODE_CASES = [
     (8, 8, 112, 16, torch.float16, [129, 16]),
     (6, 2, 120, 16, torch.bfloat16, [200, 31]),
     (8, 2, 192, 16, torch.bfloat16, [90, 513]),
-    (8, 2, 192, 32, torch.float16, [65, 300]),
+    (8, 2, 192, 32, torch.float16, [65, 300]),        # generic path (head size 192 with 32-token blocks)
+    # every head size of the reference's op (vllm/attention/ops/paged_attn.py:37) on the matrix-core
+    # kernel, lengths on and around the 32-token tile and long enough for several KV splits
+    (8, 8, 32, 16, torch.bfloat16, [1, 31, 32, 33, 1500]),
+    (16, 4, 80, 16, torch.float16, [1, 16, 17, 33, 2100]),
+    (64, 8, 80, 16, torch.bfloat16, [120, 4000]),      # test_attention.py:36 (64, 8) head geometry
+    (16, 2, 96, 16, torch.bfloat16, [1, 32, 47, 2049, 784]),
+    (16, 2, 112, 16, torch.bfloat16, [15, 16, 64, 1999]),
+    (40, 40, 120, 16, torch.float16, [1, 33, 500]),
+    (16, 2, 120, 16, torch.bfloat16, [31, 3000]),
+    (32, 8, 192, 16, torch.bfloat16, [1, 17, 32, 777, 2500]),
+    (16, 16, 192, 16, torch.float16, [40, 1030]),
 ]
 
 
@@ -504,13 +515,25 @@ PREFILL_CASES = [
     (32, 8, 64, torch.bfloat16, [513, 64], [513, 64]),       # Llama-3.2-1B
     (12, 12, 64, torch.float16, [333, 64], [333, 64]),
     (8, 8, 64, torch.bfloat16, [150], [100]),
-    (4, 4, 80, torch.bfloat16, [70, 33], [48, 33]),     # generic path
-    (4, 2, 64, torch.float32, [50], [50]),               # generic path
-    (4, 2, 96, torch.bfloat16, [90, 17], [60, 17]),      # generic path
-    (4, 4, 112, torch.float16, [65], [65]),              # generic path
-    (6, 2, 120, torch.bfloat16, [40, 130], [40, 100]),   # generic path
-    (4, 1, 192, torch.bfloat16, [150], [150]),           # generic path
-    (8, 2, 256, torch.float16, [70, 129], [70, 96]),     # generic path
+    (4, 2, 64, torch.float32, [50], [50]),               # generic path (f32)
+    # the other head sizes of the reference's op (vllm/attention/ops/paged_attn.py:37) on the
+    # matrix-core kernel: 32 in 64-element rows, 80 - 120 in 128-element rows, 192 and 256 in
+    # 256-element rows (8-wave workgroups); prompts of one tile, several tiles, ragged, pruned
+    (4, 4, 80, torch.bfloat16, [70, 33], [48, 33]),
+    (4, 2, 96, torch.bfloat16, [90, 17], [60, 17]),
+    (4, 4, 112, torch.float16, [65], [65]),
+    (6, 2, 120, torch.bfloat16, [40, 130], [40, 100]),
+    (4, 1, 192, torch.bfloat16, [150], [150]),
+    (8, 2, 256, torch.float16, [70, 129], [70, 96]),
+    (8, 2, 32, torch.bfloat16, [1, 64, 65, 300], [1, 64, 65, 300]),
+    (8, 8, 80, torch.float16, [513, 128, 1], [513, 96, 1]),
+    (16, 4, 96, torch.bfloat16, [700, 129], [512, 129]),
+    (4, 1, 112, torch.bfloat16, [1024], [768]),
+    (8, 4, 120, torch.float16, [257, 600], [257, 600]),
+    (8, 2, 192, torch.bfloat16, [1, 127, 128, 129, 640], [1, 127, 128, 129, 400]),
+    (16, 16, 192, torch.float16, [300], [300]),
+    (8, 2, 256, torch.bfloat16, [1024, 63], [768, 63]),
+    (32, 8, 256, torch.bfloat16, [385], [385]),
 ]
 
 
@@ -529,6 +552,34 @@ def test_prefill_causal(ops, oracle, Hq, Hkv, D, dtype, q_lens, kv_lens):
     # tolerance vs an f32 evaluation of the same inputs (bf16: atol 2e-2, rtol 1.6e-2)
     tol = {torch.bfloat16: (2e-2, 1.6e-2), torch.float16: (3e-3, 1e-2), torch.float32: (1e-4, 1e-4)}[dtype]
     torch.testing.assert_close(out.cpu().float(), ref, atol=tol[0], rtol=tol[1])
+
+
+@pytest.mark.parametrize("D", [32, 80, 96, 112, 120, 192, 256])
+def test_prefill_matrix_core_kernel_against_the_general_one(ops, D, monkeypatch):
+    """The two prefill kernels on the same ragged batch: the matrix-core kernel (rows padded to
+    64 / 128 / 256 elements inside the kernel) and the general one (PE_PREFILL_FORCE_GENERIC=1),
+    which walks exactly head_size elements."""
+    g = torch.Generator().manual_seed(D)
+    Hq, Hkv = 8, 2
+    q_lens, kv_lens = [200, 1, 333, 64], [200, 1, 208, 64]
+    q = (torch.rand(sum(q_lens), Hq, D, generator=g) * 2 - 1).to(torch.bfloat16).cuda()
+    k = (torch.rand(sum(kv_lens), Hkv, D, generator=g) * 2 - 1).to(torch.bfloat16).cuda()
+    v = (torch.rand(sum(kv_lens), Hkv, D, generator=g) * 2 - 1).to(torch.bfloat16).cuda()
+    cq, ck = _cu(q_lens).cuda(), _cu(kv_lens).cuda()
+    fast = ops.prefill_causal(q, k, v, cq, ck, max(q_lens), D ** -0.5)
+    monkeypatch.setenv("PE_PREFILL_FORCE_GENERIC", "1")
+    slow = ops.prefill_causal(q, k, v, cq, ck, max(q_lens), D ** -0.5)
+    assert not torch.equal(fast, slow) or D == 0          # two kernels, two summation orders
+    torch.testing.assert_close(fast.float(), slow.float(), atol=2e-2, rtol=1.6e-2)
+    # strided views of a fused qkv buffer (what the model hands over) give the same bits
+    qkv = torch.zeros(sum(q_lens), (Hq + 2 * Hkv) * D, dtype=torch.bfloat16, device="cuda")
+    if q_lens == kv_lens:
+        return
+    monkeypatch.delenv("PE_PREFILL_FORCE_GENERIC")
+    qv = qkv[:, :Hq * D].view(-1, Hq, D)
+    qv.copy_(q)
+    again = ops.prefill_causal(qv, k, v, cq, ck, max(q_lens), D ** -0.5)
+    assert torch.equal(again, fast)
 
 
 def test_prefill_reference_sdpa_forward_golden(ops):
@@ -719,13 +770,21 @@ def disjoint_tables(lens, bs, nb, g):
 
 
 @pytest.mark.parametrize("Hq,Hkv,D,dtype", [(32, 8, 128, torch.bfloat16), (12, 12, 64, torch.float16),
-                                            (8, 1, 128, torch.bfloat16)])
+                                            (8, 1, 128, torch.bfloat16), (8, 2, 32, torch.bfloat16),
+                                            (8, 2, 80, torch.bfloat16), (12, 4, 96, torch.float16),
+                                            (8, 8, 112, torch.bfloat16), (6, 2, 120, torch.bfloat16),
+                                            (8, 2, 192, torch.bfloat16), (16, 2, 256, torch.float16)])
 @pytest.mark.parametrize("splits", [0, 3])
 @pytest.mark.parametrize("bs", [16, 8, 32])
 def test_decode_step_fused_write(ops, oracle, Hq, Hkv, D, dtype, splits, bs, monkeypatch):
     """One launch (KV write + attention) == reshape_and_cache followed by paged attention:
     cache bytes identical, outputs within the kernel tolerance.  Block sizes 8, 16 and 32 (the
-    page sizes of the reference's scripts/diff_page_sizes.sh) all run the MFMA kernel."""
+    page sizes of the reference's scripts/diff_page_sizes.sh) all run the MFMA kernel for head
+    sizes 64 and 128; every other head size of the reference's op (paged_attn.py:37) runs it with
+    16-token blocks."""
+    if bs != 16 and D not in (64, 128):
+        assert not ops._lib.load().pe_paged_decode_supports_fused_write(Hq, Hkv, D, bs, 2)
+        pytest.skip("8- and 32-token blocks are built for head sizes 64 and 128")
     if splits:
         monkeypatch.setenv("PE_DECODE_SPLITS", str(splits))
     g = torch.Generator().manual_seed(Hq + D)

@@ -5,7 +5,10 @@
 // the reference runs when the prompt was pruned before attention (L_kv < L_q).
 // Grouped KV heads are addressed directly (no repeat_interleave copy).
 //
-// MFMA path (16-bit types, head_size 64/128): a workgroup of 4 waves owns 128 query rows of
+// MFMA path (16-bit types; head sizes 64 and 128 as they are, 256 with 8-wave workgroups, and the
+// other sizes of the reference's list - 32, 80, 96, 112, 120, 192, vllm/attention/ops/paged_attn.py:37 -
+// in the next larger of those row pitches with the chunks past the head never used):
+// a workgroup of 4 waves owns 128 query rows of
 // one (request, head); K/V tiles of 64 tokens stream global -> LDS directly (LDS-DMA loads,
 // double-buffered: tile j+1 is in flight during the math of tile j).
 //   S^T = K.Q^T   v_mfma_f32_16x16x32: A = K rows from LDS (ds_read_b128, XOR-swizzled
@@ -33,7 +36,7 @@ __device__ __forceinline__ int swz_off(int row, int chunk) {
   // byte offset of 16-byte chunk `chunk` of row `row` in the [rows][D] 16-bit K tile: the 16 rows
   // a ds_read_b128 lane group touches land on 16 different 16-byte slots of the 256-byte bank row
   constexpr int CPR = D / 8;
-  const int x = (CPR == 16) ? (row & 15) : ((row >> 1) & 7);
+  const int x = (CPR >= 16) ? (row & 15) : ((row >> 1) & 7);
   return row * (D * 2) + ((chunk ^ x) << 4);
 }
 
@@ -43,12 +46,14 @@ __device__ __forceinline__ int swz_off_v(int row, int chunk) {
   // pair per row); XOR-ing the pair index with the row puts the 8 rows on 8 different 32-byte
   // spans of the bank row
   constexpr int CPR = D / 8;
-  const int x = (CPR == 16) ? ((row & 7) << 1) : (((row >> 1) & 3) << 1);
+  const int x = (CPR >= 16) ? ((row & 7) << 1) : (((row >> 1) & 3) << 1);
   return row * (D * 2) + ((chunk ^ x) << 4);
 }
 
-// NR: 16-row query tiles per wave; WAVES: waves per workgroup (query rows per workgroup =
-// 16 * NR * WAVES); WPE: waves per SIMD the register budget is cut for.
+// D: row pitch of the K/V tiles in LDS and width of the fragment loops (64, 128 or 256 elements);
+// the head itself has head_size <= D elements (a multiple of 8).  NR: 16-row query tiles per wave;
+// WAVES: waves per workgroup (query rows per workgroup = 16 * NR * WAVES); WPE: waves per SIMD the
+// register budget is cut for.
 // max over the four lanes l, l^16, l^32, l^48 with the row-swap permutes (VALU, no LDS round
 // trip as a ds_bpermute shuffle would take): v_permlane32_swap exchanges the upper half of its
 // first operand with the lower half of its second, v_permlane16_swap the odd 16-lane rows of the
@@ -67,8 +72,8 @@ template <typename T, int D, int NR, int WAVES, int WPE>
 __global__ __launch_bounds__(WAVES * 64, WPE) void prefill_mfma_kernel(
     T* __restrict__ out, const T* __restrict__ q, const T* __restrict__ k,
     const T* __restrict__ v, const int32_t* __restrict__ cu_q, const int32_t* __restrict__ cu_kv,
-    int num_heads, int num_kv_heads, int64_t q_stride, int64_t k_stride, int64_t v_stride,
-    int64_t out_stride, float scale_log2e) {
+    int num_heads, int num_kv_heads, int head_size, int64_t q_stride, int64_t k_stride,
+    int64_t v_stride, int64_t out_stride, float scale_log2e) {
   using TR = Traits<T>;
   using vec8 = typename TR::vec8;
   constexpr int KS = D / 32;
@@ -114,16 +119,21 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void prefill_mfma_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, c = lane & 15;
   const int wrow0 = m0 + wave * WROWS;  // first query row of this wave
+  const int hchunks = head_size >> 3;   // 16-byte chunks of a head row that exist (<= CPR)
 
   // ---- Q fragments (B operand): lane holds Q[row][32ks + 8g .. +8) for its row tiles ----
   vec8 qf[NR][KS];
 #pragma unroll
   for (int n = 0; n < NR; ++n) {
     const int row = min(wrow0 + n * 16 + c, lq - 1);
-    const T* qp = q + (int64_t)(q0 + row) * q_stride + (int64_t)head * D + 8 * g;
+    const T* qp = q + (int64_t)(q0 + row) * q_stride + (int64_t)head * head_size + 8 * g;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-      qf[n][ks] = __builtin_bit_cast(vec8, *reinterpret_cast<const u32x4*>(qp + 32 * ks));
+    for (int ks = 0; ks < KS; ++ks) {
+      // a chunk past the head is zero in Q, so whatever its K slot holds contributes nothing
+      u32x4 raw = {0u, 0u, 0u, 0u};
+      if (4 * ks + g < hchunks) raw = *reinterpret_cast<const u32x4*>(qp + 32 * ks);
+      qf[n][ks] = __builtin_bit_cast(vec8, raw);
+    }
   }
 
   // The row sums ride on the matrix pipe: one more MFMA per P fragment with an all-ones A operand
@@ -162,12 +172,16 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void prefill_mfma_kernel(
   static_assert(RSTEP % 16 == 0 && NINST >= 1 && NINST * RSTEP == PF_BN, "staging shape");
   const int lrow = wave * RPI + lane / CPR;  // row within a RSTEP group
   const int lslot = lane % CPR;
-  const char* k_seq = reinterpret_cast<const char*>(k + (int64_t)kv0 * k_stride + (int64_t)kvh * D);
-  const char* v_seq = reinterpret_cast<const char*>(v + (int64_t)kv0 * v_stride + (int64_t)kvh * D);
+  const char* k_seq = reinterpret_cast<const char*>(k + (int64_t)kv0 * k_stride + (int64_t)kvh * head_size);
+  const char* v_seq = reinterpret_cast<const char*>(v + (int64_t)kv0 * v_stride + (int64_t)kvh * head_size);
   const uint32_t k_row_bytes = (uint32_t)k_stride * 2u, v_row_bytes = (uint32_t)v_stride * 2u;
   // source chunk for this lane's slot: the inverse of swz_off / swz_off_v (XOR is an involution)
-  const uint32_t k_chunk16 = (uint32_t)(swz_off<D>(lrow, lslot) - lrow * (D * 2));
-  const uint32_t v_chunk16 = (uint32_t)(swz_off_v<D>(lrow, lslot) - lrow * (D * 2));
+  // (a slot whose chunk lies past the head is filled with the row's chunk 0 instead: finite data
+  //  that meets the zero chunk of Q, or - in V - feeds output columns nobody stores)
+  uint32_t k_chunk16 = (uint32_t)(swz_off<D>(lrow, lslot) - lrow * (D * 2));
+  uint32_t v_chunk16 = (uint32_t)(swz_off_v<D>(lrow, lslot) - lrow * (D * 2));
+  if ((int)(k_chunk16 >> 4) >= hchunks) k_chunk16 = 0;
+  if ((int)(v_chunk16 >> 4) >= hchunks) v_chunk16 = 0;
   const uint32_t k_lane_off = (uint32_t)lrow * k_row_bytes + k_chunk16;
   const uint32_t v_lane_off = (uint32_t)lrow * v_row_bytes + v_chunk16;
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem +
@@ -365,8 +379,8 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void prefill_mfma_kernel(
     const int x = row & 15;
     const u32x2 lo = *reinterpret_cast<const u32x2*>(o_lds + row * (D * 2) + (((2 * ch) ^ x) << 3));
     const u32x2 hi = *reinterpret_cast<const u32x2*>(o_lds + row * (D * 2) + (((2 * ch + 1) ^ x) << 3));
-    if (qrow < lq) {
-      *reinterpret_cast<u32x4*>(out + (int64_t)(q0 + qrow) * out_stride + (int64_t)head * D + ch * 8) =
+    if (qrow < lq && ch < hchunks) {
+      *reinterpret_cast<u32x4*>(out + (int64_t)(q0 + qrow) * out_stride + (int64_t)head * head_size + ch * 8) =
           u32x4{lo[0], lo[1], hi[0], hi[1]};
     }
   }
@@ -435,7 +449,11 @@ extern "C" int pe_prefill_causal(void* out, const void* q, const void* k, const 
              PE_ERR_INVALID_ARG, "prefill: bad head layout");
   PE_REQUIRE(num_seqs <= 65535 && num_heads <= 65535, PE_ERR_UNSUPPORTED, "prefill: grid too large");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const bool mfma = (dtype == PE_BF16 || dtype == PE_F16) && (head_size == 64 || head_size == 128) &&
+  const bool hs_ok = head_size == 32 || head_size == 64 || head_size == 80 || head_size == 96 ||
+                     head_size == 112 || head_size == 120 || head_size == 128 || head_size == 192 ||
+                     head_size == 256;
+  static EnvInt force_generic("PE_PREFILL_FORCE_GENERIC", 0);
+  const bool mfma = (dtype == PE_BF16 || dtype == PE_F16) && hs_ok && !force_generic.get() &&
                     scale > 0.f && max_q_len / 64 < 65535 &&
                     k_stride > 0 && v_stride > 0 && k_stride < (1 << 24) && v_stride < (1 << 24) &&
                     q_stride % 8 == 0 && k_stride % 8 == 0 && v_stride % 8 == 0 &&
@@ -475,9 +493,13 @@ extern "C" int pe_prefill_causal(void* out, const void* q, const void* k, const 
     const int bm = 16 * NR * WAVES;                                                                \
     dim3 grid((unsigned)num_heads, (unsigned)num_seqs, (unsigned)((max_q_len + bm - 1) / bm));     \
     const size_t lds = 4 * (size_t)PF_BN * HS * 2;                                                 \
+    if (lds > 64 * 1024)                                                                           \
+      (void)hipFuncSetAttribute(                                                                   \
+          reinterpret_cast<const void*>(&prefill_mfma_kernel<T, HS, NR, WAVES, WPE>),              \
+          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                   \
     hipLaunchKernelGGL((prefill_mfma_kernel<T, HS, NR, WAVES, WPE>), grid, dim3(WAVES * 64), lds,  \
                        st, (T*)out, (const T*)q, (const T*)k, (const T*)v, cu_q, cu_kv, num_heads, \
-                       num_kv_heads, q_stride, k_stride, v_stride, out_stride, sl2);               \
+                       num_kv_heads, head_size, q_stride, k_stride, v_stride, out_stride, sl2);    \
   } while (0)
 #define PE_LAUNCH_PF_SHAPE(T, HS)                                                                  \
   do {                                                                                             \
@@ -488,9 +510,12 @@ extern "C" int pe_prefill_causal(void* out, const void* q, const void* k, const 
       default: PE_LAUNCH_PF(T, HS, 2, 4, 2); break;                                                \
     }                                                                                              \
   } while (0)
+    // row pitch 256 (head sizes 192, 256): four 64-row tiles of K and V take 128 KiB of LDS, so
+    // one workgroup per CU - 8 waves x 16 rows, whose staging writes 16 tile rows per step
     PE_DISPATCH_16(dtype, T, {
-      if (head_size == 64) PE_LAUNCH_PF_SHAPE(T, 64);
-      else PE_LAUNCH_PF_SHAPE(T, 128);
+      if (head_size <= 64) PE_LAUNCH_PF_SHAPE(T, 64);
+      else if (head_size <= 128) PE_LAUNCH_PF_SHAPE(T, 128);
+      else PE_LAUNCH_PF(T, 256, 1, 8, 2);
     });
 #undef PE_LAUNCH_PF_SHAPE
 #undef PE_LAUNCH_PF
