@@ -145,11 +145,12 @@ int pe_reshape_and_cache(const void* key, const void* value, void* key_cache,
  *                  may be NULL when that function returns 0.  Calls that overlap on one
  *                  workspace (different streams) race on it.
  * softmax follows the CUDA kernel: p = exp(l - max) / (sum + 1e-6) (:342).
- * Kernel choice: 16-bit dtypes with block_size 16 (head_size 64/128/256) or block_size 8/32
- * (head_size 64/128), up to 16 query heads per KV head and strides that are multiples of 8
- * elements run the matrix-core kernel, which reads K/V once per KV head; everything else the
- * reference's op accepts (other head sizes of paged_attn.py:37, f32, other block sizes) runs a
- * general kernel with the same results and no tuning.
+ * Kernel choice: 16-bit dtypes with block_size 16 (every head size of the reference's op,
+ * vllm/attention/ops/paged_attn.py:37: 32, 64, 80, 96, 112, 120, 128, 192, 256) or block_size
+ * 8/32 (head_size 64/128), up to 16 query heads per KV head and strides that are multiples of 8
+ * elements run the matrix-core kernel, which reads K/V once per KV head; everything else (f32,
+ * other block sizes, more query heads per KV head) runs a general kernel with the same results
+ * and no tuning.
  * ---------------------------------------------------------------------------------- */
 int64_t pe_paged_decode_workspace_bytes(int num_seqs, int num_heads, int num_kv_heads,
                                         int head_size, int block_size, int max_seq_len);
@@ -218,8 +219,9 @@ int pe_decode_step(void* out, const void* query, const void* new_key, const void
  * storage type), so the result and the cache bytes equal those of pe_rope_reshape_and_cache
  * followed by pe_paged_decode.  A sequence whose slot is negative is not cached, its query is
  * still rotated and its new key row is ignored, as in pe_decode_step.  rot_dim must be a multiple
- * of 64 (NeoX pairing) or 16 (GPT-J pairing), head_size 64 or 128, and the shape one
- * pe_paged_decode_supports_fused_write accepts; otherwise PE_ERR_UNSUPPORTED, nothing written. */
+ * of 64 (NeoX pairing) or 16 (GPT-J pairing), head_size 64 or 128 (block_size 8, 16 or 32), and
+ * the shape one pe_paged_decode_supports_fused_write accepts; otherwise PE_ERR_UNSUPPORTED, nothing
+ * written. */
 int pe_decode_step_rope(void* out, const void* query, const void* new_key, const void* new_value,
                         void* key_cache, void* value_cache, const int64_t* slot_mapping,
                         const int32_t* block_tables, const int32_t* seq_lens,

@@ -966,7 +966,8 @@ def test_rope_reshape_and_cache(ops, oracle, dtype, is_neox, Hq, Hkv, D, rot):
 @pytest.mark.parametrize("Hq,Hkv,D,rot", [(32, 8, 128, 128), (12, 12, 64, 64), (8, 1, 128, 64),
                                           (8, 2, 128, 48)])
 @pytest.mark.parametrize("splits", [0, 3])
-def test_decode_step_rope(ops, oracle, dtype, is_neox, Hq, Hkv, D, rot, splits, monkeypatch):
+@pytest.mark.parametrize("bs", [16, 8, 32])
+def test_decode_step_rope(ops, oracle, dtype, is_neox, Hq, Hkv, D, rot, splits, bs, monkeypatch):
     """One launch (rotary embedding + KV write + attention) == the oracle's rotary embedding, KV
     write and paged attention: the cache receives the rotated key byte for byte, the output equals
     the two-launch form (rotary_embedding_and_cache, then decode_step's unfused twin) bit for bit
@@ -976,7 +977,7 @@ def test_decode_step_rope(ops, oracle, dtype, is_neox, Hq, Hkv, D, rot, splits, 
     if splits:
         monkeypatch.setenv("PE_DECODE_SPLITS", str(splits))
     g = torch.Generator().manual_seed(Hq + D + rot + int(is_neox))
-    bs, nb, max_pos = 16, 400, 4096
+    nb, max_pos = 6400 // bs, 4096
     lens = [1, 16, 17, 32, 33, 700, 784, 2000]       # kv length including the new token
     S = len(lens)
     sc = D ** -0.5

@@ -631,17 +631,15 @@ class PagedEvictImpl(_ImplBase):
                 and self.paged_evict_config.cache_prune_type == "budget" \
                 and self.paged_evict_config.evict_method in ("streamingLLM-1", "inverse_key_l2"):
             self._note_cache(kv_cache)      # the methods that zero evicted slots (all layers at once)
-        rope_dec = None
+        rope_dec = rope_pre = None
         if rope is not None:
             positions, cos_sin, is_neox = rope
             nt = attn_metadata.num_prefill_tokens
-            if nt > 0:
-                ops.rotary_embedding(positions[:nt], query[:nt], key[:nt], self.head_size, cos_sin,
-                                     is_neox)
+            rope_pre = (positions[:nt], cos_sin, is_neox)
             rope_dec = (positions[nt:], cos_sin, is_neox)
         if (pm := attn_metadata.prefill_metadata) is not None:
             self._forward_prefill(out, query, key, value, key_cache, value_cache, attn_metadata, pm,
-                                  is_profile_run)
+                                  is_profile_run, rope_pre)
         if (dm := attn_metadata.decode_metadata) is not None:
             self._forward_decode(out, query, key, value, key_cache, value_cache, attn_metadata, dm,
                                  kv_cache, rope_dec)
@@ -649,7 +647,15 @@ class PagedEvictImpl(_ImplBase):
 
     # ------------------------------------------------------------------------------ prefill
     def _forward_prefill(self, out, query, key, value, key_cache, value_cache, meta, pm,
-                         is_profile_run) -> None:
+                         is_profile_run, rope=None) -> None:
+        """``rope`` = (positions of the prompt rows, cos_sin_cache, is_neox): the prompt rows arrive
+        unrotated and are rotated in place here - in the same launch as the KV write
+        (pe_rope_reshape_and_cache: the two launches that precede attention in the model,
+        vllm/model_executor/models/llama.py:202-205, as one) whenever the rows the cache keeps are
+        known without looking at the data: no prune, or the streamingLLM prune with attention over
+        the full prompt (the kept rows depend on the lengths only).  A token-level prune scores
+        the ROTATED keys, and a prune in front of attention gathers rotated rows: those rotate in
+        a launch of their own first."""
         nt = meta.num_prefill_tokens
         q, k, v = query[:nt], key[:nt], value[:nt]
         seq_lens = pm.seq_lens
@@ -662,6 +668,13 @@ class PagedEvictImpl(_ImplBase):
         cfg = self.paged_evict_config
         pruner = self.kv_cache_pruner
         prune = self.enabled_paged_eviction and any(pruner.prunes(L) for L in seq_lens)
+        fuse_rope_write = False
+        if rope is not None and nt > 0:
+            fuse_rope_write = not is_profile_run and (
+                not prune or (cfg.disable_evict_prefill and not self.compat.prompt_prune_cross_head
+                              and pruner.evict_method in ("streamingLLM", "streamingLLM-1")))
+            if not fuse_rope_write:
+                ops.rotary_embedding(rope[0], q, k, self.head_size, rope[1], rope[2])
 
         src_index = kept = None
         if prune:
@@ -691,9 +704,29 @@ class PagedEvictImpl(_ImplBase):
                                                     self.kv_cache_dtype, 1.0, 1.0)
                 self._prompt_block_scores(pv, kept, meta, pk)
         else:
+            if fuse_rope_write:
+                # one launch: rotation of the prompt's query/key rows + KV write of the rows the
+                # cache keeps (a pruned-away row has slot -1: rotated for attention, not cached)
+                slots = meta.slot_mapping[:nt]
+                if prune:
+                    slots = step.get("rope_slots")
+                    if slots is None:
+                        n_kept = src_index.shape[0]
+                        slots = torch.full((nt,), -1, dtype=torch.int64, device=q.device)
+                        slots.index_copy_(0, src_index.to(torch.int64), meta.slot_mapping[:n_kept])
+                        step["rope_slots"] = slots      # lengths only: shared by the step's layers
+                ops.rotary_embedding_and_cache(rope[0], q, k, v, key_cache, value_cache, slots,
+                                               self.head_size, rope[1], rope[2])
             ops.prefill_causal(q, k, v, cu_q, cu_q, max_q, self.scale, out=out[:nt])
             if not is_profile_run:
-                if prune:
+                if fuse_rope_write:
+                    if prune:
+                        if self._needs_scores():
+                            pk, pv = ops.prompt_prune_gather(k, v, src_index, mode=None)
+                            self._prompt_block_scores(pv, kept, meta, pk)
+                    elif self.enabled_paged_eviction:
+                        self._prompt_block_scores(v, list(seq_lens), meta, k)
+                elif prune:
                     n_kept = src_index.shape[0]
                     PagedAttention.write_to_paged_cache(
                         k, v, key_cache, value_cache, meta.slot_mapping[:n_kept],

@@ -262,6 +262,36 @@ static bool mfma_path_ok(int num_heads, int num_kv_heads, int head_size, int blo
   return true;
 }
 
+// Instantiation choice for head sizes 64 / 128 / 256: waves per workgroup (4, 8, or - plain form,
+// 16-token blocks, head sizes up to 128 - 16), rotating form or not, tokens per block.
+template <typename T, int HS, int B>
+static void dispatch_dec_block(const DecLaunch& la, int waves) {
+  if (la.rope != nullptr) {
+    if constexpr (HS <= 128) {
+      if (waves == 8) launch_dec<T, HS, 8, true, B>(la);
+      else launch_dec<T, HS, DEC_WAVES, true, B>(la);
+    }
+    return;
+  }
+  if constexpr (B == 16 && HS <= 128) {
+    if (waves == 16) {
+      launch_dec<T, HS, 16, false, 16>(la);
+      return;
+    }
+  }
+  if (waves == 8) launch_dec<T, HS, 8, false, B>(la);
+  else launch_dec<T, HS, DEC_WAVES, false, B>(la);
+}
+
+template <typename T, int HS>
+static void dispatch_dec(const DecLaunch& la, int waves, int block_size) {
+  if constexpr (HS <= 128) {
+    if (block_size == 32) return dispatch_dec_block<T, HS, 32>(la, waves);
+    if (block_size == 8) return dispatch_dec_block<T, HS, 8>(la, waves);
+  }
+  dispatch_dec_block<T, HS, 16>(la, waves);
+}
+
 int decode_diag_fetch(unsigned int* out, int reset) {
   unsigned int a = 0, b = 0;
   if (int rc = decode_diag_fetch_tu(&a, reset)) return rc;
@@ -331,60 +361,17 @@ static int decode_impl(void* out, const void* query, const void* key_cache, cons
                  num_heads, num_kv_heads, max_num_blocks_per_seq, q_stride, kv_block_stride,
                  kv_head_stride, scale, splits, new_key, new_value, new_slots, new_k_stride,
                  new_v_stride, num_slots, rope, grid, lds, st};
-#define PE_LAUNCH_DEC_WR(T, HS, W, R) launch_dec<T, HS, W, R, 16>(la)
-#define PE_LAUNCH_DEC_W(T, HS, W) launch_dec<T, HS, W, false, 16>(la)
-#define PE_LAUNCH_DEC_B(T, HS, W, B) launch_dec<T, HS, W, false, B>(la)
-#define PE_LAUNCH_DEC(T, HS)                               \
-  do {                                                     \
-    if (block_size != 16) {                                \
-      if constexpr (HS <= 128) {                           \
-        if (block_size == 32) {                            \
-          if (waves == 8) {                                \
-            PE_LAUNCH_DEC_B(T, HS, 8, 32);                 \
-          } else {                                         \
-            PE_LAUNCH_DEC_B(T, HS, DEC_WAVES, 32);         \
-          }                                                \
-        } else {                                           \
-          if (waves == 8) {                                \
-            PE_LAUNCH_DEC_B(T, HS, 8, 8);                  \
-          } else {                                         \
-            PE_LAUNCH_DEC_B(T, HS, DEC_WAVES, 8);          \
-          }                                                \
-        }                                                  \
-      }                                                    \
-    } else if (rope != nullptr) {                          \
-      if constexpr (HS <= 128) {                           \
-        if (waves == 8) {                                  \
-          PE_LAUNCH_DEC_WR(T, HS, 8, true);                \
-        } else {                                           \
-          PE_LAUNCH_DEC_WR(T, HS, DEC_WAVES, true);        \
-        }                                                  \
-      }                                                    \
-    } else if (waves == 16) {                              \
-      if constexpr (HS <= 128) {                           \
-        PE_LAUNCH_DEC_W(T, HS, 16);                        \
-      }                                                    \
-    } else if (waves == 8) {                               \
-      PE_LAUNCH_DEC_W(T, HS, 8);                           \
-    } else {                                               \
-      PE_LAUNCH_DEC_W(T, HS, DEC_WAVES);                   \
-    }                                                      \
-  } while (0)
     if (head_size != 64 && head_size != 128 && head_size != 256) {
       // the other head sizes: 16-token blocks, no rotation (mfma_path_ok / the entry points
       // have seen to that), 4- or 8-wave workgroups
       if (int rc = launch_decode_other_heads(la, head_size, waves >= 8 ? 8 : DEC_WAVES, dtype)) return rc;
     } else {
       PE_DISPATCH_16(dtype, T, {
-        if (head_size == 64) PE_LAUNCH_DEC(T, 64);
-        else if (head_size == 128) PE_LAUNCH_DEC(T, 128);
-        else PE_LAUNCH_DEC(T, 256);
+        if (head_size == 64) dispatch_dec<T, 64>(la, waves, block_size);
+        else if (head_size == 128) dispatch_dec<T, 128>(la, waves, block_size);
+        else dispatch_dec<T, 256>(la, waves, block_size);
       });
     }
-#undef PE_LAUNCH_DEC
-#undef PE_LAUNCH_DEC_B
-#undef PE_LAUNCH_DEC_W
-#undef PE_LAUNCH_DEC_WR
     if (int rc = check_launch("paged_decode")) return rc;
     if (splits > 1) {
 #define PE_LAUNCH_MERGE(T, MS)                                                                   \
@@ -503,13 +490,10 @@ int pe_decode_step_rope(void* out, const void* query, const void* new_key, const
   PE_REQUIRE(mfma_path_ok(num_heads, num_kv_heads, head_size, block_size, dtype, q_stride,
                           kv_block_stride, kv_head_stride),
              PE_ERR_UNSUPPORTED,
-             "decode_step_rope needs the MFMA decode path (16-bit dtype, block_size 16, head_size "
+             "decode_step_rope needs the MFMA decode path (16-bit dtype, block_size 8/16/32, head_size "
              "64/128, strides multiples of 8): use pe_rope_reshape_and_cache + pe_paged_decode");
-  PE_REQUIRE(block_size == 16, PE_ERR_UNSUPPORTED,
-             "decode_step_rope is built for 16-token blocks; use pe_rope_reshape_and_cache + "
-             "pe_paged_decode");
-  PE_REQUIRE(head_size <= 128, PE_ERR_UNSUPPORTED,
-             "decode_step_rope: head_size %d has no registers left for the rotation; use "
+  PE_REQUIRE(head_size == 64 || head_size == 128, PE_ERR_UNSUPPORTED,
+             "decode_step_rope is built for head sizes 64 and 128 (head_size %d): use "
              "pe_rope_reshape_and_cache + pe_paged_decode", head_size);
   // both elements of a rotation pair must sit in one lane of the fragment layout
   PE_REQUIRE(rot_dim > 0 && rot_dim <= head_size &&

@@ -783,7 +783,7 @@ def decode_step_rope_supported(num_heads: int, num_kv_heads: int, head_size: int
     code = _lib.PE_BF16 if dtype == torch.bfloat16 else _lib.PE_F16
     if not lib.pe_paged_decode_supports_fused_write(num_heads, num_kv_heads, head_size, block_size, code):
         return False
-    return (block_size == 16 and head_size <= 128 and 0 < rot_dim <= head_size
+    return (block_size in (8, 16, 32) and head_size in (64, 128) and 0 < rot_dim <= head_size
             and rot_dim % (64 if is_neox else 16) == 0)
 
 
