@@ -591,15 +591,38 @@ def workload_name(a, wl) -> str:
                if wl.cfg is not None else "no eviction"))
 
 
-def kernel_source_hash() -> str:
-    """SHA-256 over the decode kernel's sources: a stored HBM-traffic ratio is only reused for
-    the code it was measured on."""
+def kernel_source_hash(files=("paged_decode.hip", "paged_decode_kernel.h", "pe_common.h")) -> str:
+    """SHA-256 over a kernel's sources (default: the decode kernel's): a stored counter figure is
+    only reused for the code it was measured on."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("paged_decode.hip", "pe_common.h"):
+    for f in files:
         with open(os.path.join(ROOT, "vllm-paged-compression_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()
+
+
+PREFILL_SOURCES = ("prefill.hip", "pe_common.h")
+
+
+def stored_prefill_busy(flops_per_launch: float):
+    """Matrix-pipe busy fraction of the prefill kernel (SQ_VALU_MFMA_BUSY_CYCLES over SIMD cycles)
+    from the counter passes kept under profiles/, for the tracked launch shape with the same flop
+    count, measured on the same kernel source; otherwise None."""
+    import glob
+    src = kernel_source_hash(PREFILL_SOURCES)
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_prefill_pmc.json")), reverse=True):
+        try:
+            pmc = json.load(open(path))
+            if pmc.get("kernel_source_sha256") != src:
+                continue
+            for shape in pmc["shapes"].values():
+                f = shape["tflops"] * 1e12 * shape["us_per_launch"] * 1e-6
+                if abs(f / flops_per_launch - 1.0) < 0.02:
+                    return shape["mfma_pipe_busy_frac"], os.path.basename(path)
+        except Exception:
+            continue
+    return None, None
 
 
 def stored_traffic(workload: str, avg_bytes: float):
@@ -755,9 +778,11 @@ def main():
         pd = [s.elapsed_time(e) * 1e-3 for s, e, _ in wl.timed_prefill]
         pf = [f for _, _, f in wl.timed_prefill]
         ach = sum(pf) / sum(pd) / 1e12
+        busy, busy_src = stored_prefill_busy(sum(pf) / len(pf)) if world == 1 else (None, None)
         roof_p = {"bound": "mfma", "kernel": "prefill_mfma_kernel", "achieved": round(ach, 1),
                   "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
-                  "traffic": None, "avg_launch_us": round(sum(pd) / len(pd) * 1e6, 2),
+                  "traffic": None, "mfma_busy": busy, "mfma_busy_source": busy_src,
+                  "avg_launch_us": round(sum(pd) / len(pd) * 1e6, 2),
                   "flops_per_launch": int(sum(pf) / len(pf)), "launches_timed": len(pd)}
     es = 2
     blk_bytes = 2 * a.block_size * a.num_kv_heads * a.head_size * es * a.layers // max(a.emulate_tp, 1)

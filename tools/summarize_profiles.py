@@ -35,7 +35,7 @@ def read_counters(path):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "round2"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "round3"
     src = os.path.join(ROOT, "gpurun_out", "prof")
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
@@ -111,7 +111,9 @@ def main():
         }
     if pf:
         with open(os.path.join(dst, f"{tag}_prefill_pmc.json"), "w") as f:
+            from bench import PREFILL_SOURCES
             json.dump({"kernel": "prefill_mfma_kernel", "shapes": pf,
+                       "kernel_source_sha256": kernel_source_hash(PREFILL_SOURCES),
                        "notes": "mfma_pipe_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (shader cycles x 1024 "
                                 "SIMDs), shader cycles = GRBM_GUI_ACTIVE / 8 (rocprofv3 sums the 8 XCDs); "
                                 "the timed run is a separate un-profiled one"}, f, indent=1)
