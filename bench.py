@@ -202,7 +202,7 @@ class Workload:
                                  if self.cfg is not None and not self.percentage else None),
             tp_group=tp_group, total_num_kv_heads=a.num_kv_heads,
             kv_head_owner=tp_rank % max(1, tp_size // a.num_kv_heads) == 0,
-            max_num_seqs=B, max_blocks_per_seq=4 * self.blocks_per_seq_full)
+            max_num_seqs=B, max_blocks_per_seq=2 * self.blocks_per_seq_full)
             for i in range(a.layers)]
         g = torch.Generator(device=dev).manual_seed(1234 + tp_rank)
         sc = self.D ** -0.5

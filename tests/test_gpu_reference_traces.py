@@ -155,4 +155,7 @@ def test_backend_reproduces_reference_forward(trace):
         evictions += len(rmv)
         sched.commit(rmv)        # by the reported request id, as the engine does
     assert evictions == sum(len(s["rmv"]) for s in trace["steps"])
-    ops.device_diagnostics(reset=True)      # HEAD's table forms make the kernels clamp; not an error here
+    # HEAD's table forms (width M-1 for every row, the strided re-read) make the decode kernel clamp
+    # lengths to what a row addresses: that flag is expected here, any other one is not
+    flags = ops.device_diagnostics(reset=True)
+    assert flags & ~ops.DIAG_DECODE_LEN_CLAMPED == 0, f"unexpected device diagnostics {flags:#x} in {name}"

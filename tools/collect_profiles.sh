@@ -16,13 +16,15 @@ for c in ${CONFIGS:-c2 c1 c3 c4 c5}; do
   echo "== $c bench $(date +%T)"
   timeout -k 10 500 python3 "$R/bench.py" --config $c $extra > "$O/bench_$c.json" 2> "$O/bench_$c.err"
   short="--config $c $extra --no-cpu-baseline --alt-evict 0"
-  if [ "$c" != c5 ]; then
+  if true; then
     echo "== $c kernel stats $(date +%T)"
+    rshort="$short"
+    [ "$c" = c5 ] && rshort="$short --output-len 256"    # the trace of 2048 steps x 32 layers is not needed
     timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats_$c" -o bench -- \
-        python3 "$R/bench.py" $short > "$O/bench_under_rocprof_$c.json" 2> "$O/stats_$c.err"
+        python3 "$R/bench.py" $rshort > "$O/bench_under_rocprof_$c.json" 2> "$O/stats_$c.err"
     rm -f "$O/stats_$c/bench_kernel_trace.csv"
   fi
-  if [ "$c" = c2 ] || [ "$c" = c3 ]; then
+  if [ "$c" = c2 ] || [ "$c" = c3 ] || [ "$c" = c4 ]; then
     echo "== $c FETCH_SIZE $(date +%T)"
     timeout -s KILL 500 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fetch_$c" -o fetch -- \
         python3 "$R/bench.py" $short --steps 1 --warmup 0 > /dev/null 2> "$O/pmc_fetch_$c.err"
