@@ -83,7 +83,7 @@ def test_argument_checks_without_gpu():
     assert step_rope(128, 16, 48, 1) == 2 and b"rot_dim 48" in lib.pe_last_error()
     assert step_rope(256, 16, 128, 1) == 2 and b"head_size 256" in lib.pe_last_error()
     assert step_rope(128, 4, 128, 1) == 2 and b"MFMA decode path" in lib.pe_last_error()
-    assert step_rope(128, 8, 128, 1) == 2 and b"16-token blocks" in lib.pe_last_error()
+    assert step_rope(96, 16, 64, 1) == 2 and b"head sizes 64 and 128" in lib.pe_last_error()
     # (positions may be NULL - the per-step table form - so the missing pointer here is the table;
     # a NULL positions with a table of fewer rows than sequences is refused as well)
     assert lib.pe_decode_step_rope(p, p, p, p, p, p, p, p, p, None, p, None, 128, 1, 4096, 1, 32, 8, 128,
@@ -98,7 +98,9 @@ def test_argument_checks_without_gpu():
     assert ops.decode_step_rope_supported(32, 8, 128, 16, bf, 48, False)
     assert not ops.decode_step_rope_supported(32, 8, 128, 16, bf, 48, True)
     assert not ops.decode_step_rope_supported(32, 8, 256, 16, bf, 128, True)
-    assert not ops.decode_step_rope_supported(32, 8, 128, 8, bf, 128, True)
+    assert ops.decode_step_rope_supported(32, 8, 128, 8, bf, 128, True)       # 8- and 32-token blocks too
+    assert ops.decode_step_rope_supported(32, 8, 64, 32, bf, 64, True)
+    assert not ops.decode_step_rope_supported(32, 8, 96, 16, bf, 64, True)    # head sizes 64 and 128 only
     assert not ops.decode_step_rope_supported(32, 8, 128, 16, torch.float32, 128, True)
 
 
