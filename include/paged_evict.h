@@ -53,12 +53,31 @@ typedef enum {
 
 /* score formula of "local" / "global": KVCachePruner.sub_evict_method
  * (kvcache_prunner.py:13,29-66; HEAD hard-wires "value_l2").  Carried in bits 8..15 of the
- * `method` argument of pe_prompt_token_select: method | (formula << PE_SCORE_FORMULA_SHIFT). */
+ * `method` argument of pe_prompt_token_select: method | (formula << PE_SCORE_FORMULA_SHIFT).
+ * From PE_FORMULA_KEY_L1 on: the token scores of the README-era class (get_score,
+ * vllm/attention/kvcache_prunner_old.py:23-134), which the percentage prune type's prompt prune
+ * and decode-time block merge select by method name.  They are implemented as that file WRITES
+ * them, which for some is not what the name says (noted per entry). */
 typedef enum {
-  PE_FORMULA_VALUE_L2 = 0,             /* ||V||                        */
-  PE_FORMULA_KEY_L2 = 1,               /* ||K||                        */
-  PE_FORMULA_VALUE_L2_PLUS_KEY_L2 = 2, /* ||V|| + ||K||                */
-  PE_FORMULA_INVERSE_KEY_L2 = 3        /* 1 / (||K|| + 1e-8)           */
+  PE_FORMULA_VALUE_L2 = 0,             /* ||V||_2                      */
+  PE_FORMULA_KEY_L2 = 1,               /* ||K||_2                      */
+  PE_FORMULA_VALUE_L2_PLUS_KEY_L2 = 2, /* ||V||_2 + ||K||_2            */
+  PE_FORMULA_INVERSE_KEY_L2 = 3,       /* 1 / (||K||_2 + 1e-8)         */
+  PE_FORMULA_KEY_L1 = 4,               /* ||K||_1                      */
+  PE_FORMULA_VALUE_L1 = 5,             /* ||V||_1                      */
+  PE_FORMULA_INVERSE_KEY_L1 = 6,       /* 1 / (||K||_1 + 1e-8)         */
+  PE_FORMULA_KEY_L1_DIV_VALUE_L1 = 7,  /* as written (:47-48): ||K||_2 / (||V||_1 + 1e-8) */
+  PE_FORMULA_KEY_L1_DIV_VALUE_L2 = 8,  /* ||K||_1 / (||V||_2 + 1e-8)   */
+  PE_FORMULA_KEY_L2_DIV_VALUE_L1 = 9,  /* ||K||_2 / (||V||_1 + 1e-8)   */
+  PE_FORMULA_KEY_L2_DIV_VALUE_L2 = 10, /* ||K||_2 / (||V||_2 + 1e-8)   */
+  PE_FORMULA_VALUE_L1_DIV_KEY_L1 = 11, /* as written (:59-60): ||K||_1 / (||V||_1 + 1e-8) */
+  PE_FORMULA_VALUE_L1_DIV_KEY_L2 = 12, /* as written (:62-63): ||K||_1 / (||V||_2 + 1e-8) */
+  PE_FORMULA_VALUE_L2_DIV_KEY_L1 = 13, /* as written (:65-66): ||K||_2 / (||V||_1 + 1e-8) */
+  PE_FORMULA_VALUE_L2_DIV_KEY_L2 = 14, /* as written (:68-69): ||K||_2 / (||V||_2 + 1e-8) */
+  PE_FORMULA_VALUE_L1_PLUS_KEY_L1 = 15, /* ||K||_1 + ||V||_1           */
+  PE_FORMULA_COSINE = 16,              /* sum_d normalize(K)_d * normalize(V)_d (:23-27) */
+  PE_FORMULA_POSITION = 17             /* "streamingLLM" as a score: 1-based position in the
+                                          scored slice (:124-126)      */
 } pe_score_formula;
 #define PE_SCORE_FORMULA_SHIFT 8
 
@@ -501,6 +520,21 @@ int pe_merge_blocks_value_l2(void* key_cache, void* value_cache, const int32_t* 
 int pe_block_table_remove_range(int32_t* out_tables, const int32_t* block_tables,
                                 const int32_t* start, int n_remove, int batch, int max_blocks,
                                 int out_width, void* stream);
+/* pe_merge_blocks_scored: pe_merge_blocks_value_l2 with the token score chosen by `formula`
+ * (a pe_score_formula): the decode-time merge for every --decode-evict-method name get_score
+ * knows (vllm/attention/kvcache_prunner_old.py:77-134,297-315).  Scores of a token come from its
+ * key and value rows of the KV head at hand; the kept tokens are those with the HIGHEST scores.
+ * pe_token_scores: scores_out[t * num_kv_heads + h] = that score of row t, head h of dense
+ * key / value tensors [num_tokens, num_kv_heads, head_size] (f32 holding a value of the storage
+ * type; PE_FORMULA_POSITION counts rows from 1) - get_score itself, for callers and tests. */
+int pe_merge_blocks_scored(void* key_cache, void* value_cache, const int32_t* block_tables,
+                           const int32_t* rows, int n_rows, int max_blocks, int first_block,
+                           int num_block_merge, int num_kv_heads, int head_size, int block_size,
+                           int64_t kv_block_stride, int64_t kv_head_stride, int formula, int dtype,
+                           void* stream);
+int pe_token_scores(float* scores_out, const void* key, const void* value, int64_t num_tokens,
+                    int64_t key_stride, int64_t value_stride, int num_kv_heads, int head_size,
+                    int formula, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Rotary position embedding fused with the KV write - the two launches that precede the

@@ -75,6 +75,11 @@ SIGNATURES = {
                                          c_void_p]),
     "pe_block_table_remove_range": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                             c_void_p]),
+    "pe_merge_blocks_scored": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                       c_int, c_int, c_int, c_int, c_int64, c_int64, c_int, c_int,
+                                       c_void_p]),
+    "pe_token_scores": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_int,
+                                c_int, c_int, c_void_p]),
     "pe_rope_reshape_and_cache": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64,
                                           c_int, c_int, c_int, c_int, c_int, c_int64, c_int, c_int64,

@@ -13,6 +13,7 @@
 //                              written back in their original order
 //   table_remove_range_kernel  row b without columns [start[b], start[b] + n_remove)
 #include "pe_common.h"
+#include "score_formulas.h"
 
 namespace pe {
 
@@ -23,7 +24,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_blocks_kernel(
     T* __restrict__ key_cache, T* __restrict__ value_cache,
     const int32_t* __restrict__ block_tables, const int32_t* __restrict__ rows, int max_blocks,
     int first_block, int num_merge, int head_size, int block_size, int64_t kv_block_stride,
-    int64_t kv_head_stride) {
+    int64_t kv_head_stride, int formula) {
   constexpr int X = 16 / sizeof(T);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int slab = head_size * block_size;  // elements of one (block, head) slab of K or of V
@@ -49,15 +50,24 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_blocks_kernel(
   }
   __syncthreads();
 
-  // ---- 2. score of token t = ||V[t, h, :]||_2, rounded to the storage type ------------------
+  // ---- 2. score of token t: ||V[t, h, :]||_2 rounded to the storage type, or another formula
+  //         of get_score (kvcache_prunner_old.py:77-134) over the token's key and value rows ------
   if (tid < n_tok) {
     const T* v = v_s + (size_t)(tid / block_size) * slab + tid % block_size;  // V[d][tok]
-    float ss = 0.f;
-    for (int d = 0; d < head_size; ++d) {
-      const float x = to_f32(v[d * block_size]);
-      ss += x * x;
+    if (formula == PE_FORMULA_VALUE_L2) {
+      float ss = 0.f;
+      for (int d = 0; d < head_size; ++d) {
+        const float x = to_f32(v[d * block_size]);
+        ss += x * x;
+      }
+      score[tid] = round_to<T>(sqrtf(ss));
+    } else {
+      const T* k = k_s + (size_t)(tid / block_size) * slab + (tid % block_size) * X;  // K[d/X][tok][d%X]
+      score[tid] = formula_score<T>(
+          formula, head_size, tid + 1,
+          [&](int d) { return to_f32(k[(size_t)(d / X) * block_size * X + d % X]); },
+          [&](int d) { return to_f32(v[d * block_size]); });
     }
-    score[tid] = round_to<T>(sqrtf(ss));
   }
   __syncthreads();
 
@@ -127,7 +137,18 @@ int pe_merge_blocks_value_l2(void* key_cache, void* value_cache, const int32_t* 
                              int num_block_merge, int num_kv_heads, int head_size, int block_size,
                              int64_t kv_block_stride, int64_t kv_head_stride, int dtype,
                              void* stream) {
+  return pe_merge_blocks_scored(key_cache, value_cache, block_tables, rows, n_rows, max_blocks,
+                                first_block, num_block_merge, num_kv_heads, head_size, block_size,
+                                kv_block_stride, kv_head_stride, PE_FORMULA_VALUE_L2, dtype, stream);
+}
+
+int pe_merge_blocks_scored(void* key_cache, void* value_cache, const int32_t* block_tables,
+                           const int32_t* rows, int n_rows, int max_blocks, int first_block,
+                           int num_block_merge, int num_kv_heads, int head_size, int block_size,
+                           int64_t kv_block_stride, int64_t kv_head_stride, int formula, int dtype,
+                           void* stream) {
   using namespace pe;
+  PE_REQUIRE(formula_known(formula), PE_ERR_INVALID_ARG, "merge_blocks: unknown score formula %d", formula);
   PE_REQUIRE(n_rows >= 0, PE_ERR_INVALID_ARG, "negative n_rows");
   if (n_rows == 0) return PE_OK;
   PE_REQUIRE(key_cache && value_cache && block_tables && rows, PE_ERR_INVALID_ARG,
@@ -157,7 +178,8 @@ int pe_merge_blocks_value_l2(void* key_cache, void* value_cache, const int32_t* 
     hipLaunchKernelGGL(merge_blocks_kernel<T>, dim3((unsigned)n_rows, (unsigned)num_kv_heads),    \
                        dim3(MERGE_THREADS), lds, static_cast<hipStream_t>(stream), (T*)key_cache, \
                        (T*)value_cache, block_tables, rows, max_blocks, first_block,              \
-                       num_block_merge, head_size, block_size, kv_block_stride, kv_head_stride);  \
+                       num_block_merge, head_size, block_size, kv_block_stride, kv_head_stride,   \
+                       formula);                                                                  \
   } while (0)
   PE_DISPATCH_ALL(dtype, T, PE_LAUNCH_MERGE(T));
 #undef PE_LAUNCH_MERGE

@@ -13,15 +13,19 @@
 //   3. token_index_compat_kernel  (compat only) row-major (token, head) repacking of the kept
 //                              pairs, the effect of the reference's `middle[mask].view(-1,H,D)`
 #include "pe_common.h"
+#include "score_formulas.h"
 
 namespace pe {
 
 constexpr int SEL_THREADS = 256;
 
+// sortable != 0: the score is stored as an unsigned key with the order of the values (what
+// token_select_kernel's radix select walks; the cosine formula is signed); 0: the f32 score itself.
 template <typename T>
 __global__ void token_score_kernel(float* __restrict__ scores, const T* __restrict__ key,
                                    const T* __restrict__ value, int64_t total, int64_t key_stride,
-                                   int64_t value_stride, int num_heads, int head_size, int method) {
+                                   int64_t value_stride, int num_heads, int head_size, int method,
+                                   int sortable) {
   constexpr int X = 16 / sizeof(T);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
@@ -56,11 +60,15 @@ __global__ void token_score_kernel(float* __restrict__ scores, const T* __restri
     s = row_norm(kp);
   } else if (formula == PE_FORMULA_VALUE_L2_PLUS_KEY_L2) {
     s = round_to<T>(row_norm(kp) + row_norm(vp));
-  } else {
+  } else if (formula == PE_FORMULA_INVERSE_KEY_L2) {
     s = round_to<T>(row_norm(kp) + 1e-8f);
     s = round_to<T>(1.0f / s);
+  } else {
+    // the README-era formulas (cold path: element-wise reads)
+    s = formula_score<T>(formula, head_size, (int)t + 1, [&](int d) { return to_f32(kp[d]); },
+                         [&](int d) { return to_f32(vp[d]); });
   }
-  scores[i] = s;
+  scores[i] = sortable ? __uint_as_float(sortable_bits(s)) : s;
 }
 
 // exclusive prefix count of `flag` over the 256 threads of the workgroup; *total gets the sum.
@@ -282,8 +290,7 @@ int pe_prompt_token_select(int32_t* src_index, const void* key, const void* valu
     PE_REQUIRE((base == PE_EVICT_LOCAL || base == PE_EVICT_GLOBAL || base == PE_EVICT_INVERSE_KEY_L2) &&
                    (method >> 16) == 0,
                PE_ERR_INVALID_ARG, "token-level prune is defined for local/global/inverse_key_l2");
-    PE_REQUIRE(formula <= PE_FORMULA_INVERSE_KEY_L2, PE_ERR_INVALID_ARG, "unknown score formula %d",
-               formula);
+    PE_REQUIRE(formula_known(formula), PE_ERR_INVALID_ARG, "unknown score formula %d", formula);
   }
   PE_REQUIRE(block_size > 0 && (cache_budget >= 3 * block_size || (cache_budget == 0 && tail_blocks >= 1)),
              PE_ERR_INVALID_ARG,
@@ -303,7 +310,7 @@ int pe_prompt_token_select(int32_t* src_index, const void* key, const void* valu
   PE_DISPATCH_ALL(dtype, T,
                   hipLaunchKernelGGL(token_score_kernel<T>, dim3((unsigned)((total + 255) / 256)),
                                      dim3(256), 0, st, scores, (const T*)key, (const T*)value, total,
-                                     key_stride, value_stride, num_kv_heads, head_size, method));
+                                     key_stride, value_stride, num_kv_heads, head_size, method, 1));
   if (int rc = check_launch("token_score")) return rc;
   hipLaunchKernelGGL(token_select_kernel, dim3((unsigned)num_kv_heads, (unsigned)num_seqs),
                      dim3(SEL_THREADS), 0, st, src_index, flags, scores, cu_q, cu_kept, cache_budget,
@@ -316,6 +323,28 @@ int pe_prompt_token_select(int32_t* src_index, const void* key, const void* valu
     if (int rc = check_launch("token_index_compat")) return rc;
   }
   return PE_OK;
+}
+
+int pe_token_scores(float* scores_out, const void* key, const void* value, int64_t num_tokens,
+                    int64_t key_stride, int64_t value_stride, int num_kv_heads, int head_size,
+                    int formula, int dtype, void* stream) {
+  using namespace pe;
+  PE_REQUIRE(num_tokens >= 0, PE_ERR_INVALID_ARG, "negative num_tokens");
+  if (num_tokens == 0) return PE_OK;
+  PE_REQUIRE(scores_out && key && value, PE_ERR_INVALID_ARG, "token_scores: null pointer");
+  PE_REQUIRE(formula_known(formula), PE_ERR_INVALID_ARG, "unknown score formula %d", formula);
+  const int x = 16 / elem_size(dtype);
+  PE_REQUIRE(num_kv_heads > 0 && head_size > 0 && head_size % x == 0 && key_stride % x == 0 &&
+                 value_stride % x == 0,
+             PE_ERR_UNSUPPORTED, "token_scores: rows must be made of 16-byte chunks");
+  const int64_t total = num_tokens * num_kv_heads;
+  PE_DISPATCH_ALL(dtype, T,
+                  hipLaunchKernelGGL(token_score_kernel<T>, dim3((unsigned)((total + 255) / 256)),
+                                     dim3(256), 0, static_cast<hipStream_t>(stream), scores_out,
+                                     (const T*)key, (const T*)value, total, key_stride, value_stride,
+                                     num_kv_heads, head_size,
+                                     PE_EVICT_GLOBAL | (formula << PE_SCORE_FORMULA_SHIFT), 0));
+  return check_launch("token_scores");
 }
 
 }  // extern "C"
