@@ -485,7 +485,11 @@ def percentage_prompt_prune(keys: torch.Tensor, values: torch.Tensor, method: st
                                                    num_block_merge), dtype=torch.long)
         return keys[idx], values[idx]
     mk, mv = keys[end_first:end_mid], values[end_first:end_mid]
-    keep = topk_keep_mask(token_scores(mk, mv, "global" if method == "value_l2" else method), n_prune)
+    if method in ("value_l2", "inverse_key_l2"):
+        scores = token_scores(mk, mv, "global" if method == "value_l2" else method)
+    else:
+        scores = readme_token_scores(mk, mv, method)
+    keep = topk_keep_mask(scores, n_prune)
     if compat_q2:
         pk, pv = mk[keep].view(-1, H, D), mv[keep].view(-1, H, D)
     else:
@@ -515,13 +519,83 @@ def percentage_decode_blocks(seq_len: int, table_len: int, block_size: int, evic
     return initial_blocks + 1, num_block_merge - 1, (initial_blocks, initial_blocks + num_block_merge)
 
 
-def merge_keep_sets(values: torch.Tensor, n_keep: int) -> List[List[int]]:
+# get_score of the README-era pruner, vllm/attention/kvcache_prunner_old.py:23-134, by method name:
+# (operation, first norm, second norm) over the row norms kl1 = ||K||_1, kl2 = ||K||_2, vl1 = ||V||_1,
+# vl2 = ||V||_2.  AS WRITTEN there: value_*_div_key_* / value_l1_plus_key_l1 hand (key, value) to
+# helpers that apply the "value" norm to their first argument and the "key" norm to the second
+# (:59-72), and key_l1_div_value_l1 takes the key's L2 norm (:47-48).
+README_SCORES = {
+    "value_l2": ("single", "vl2", None), "key_l2": ("single", "kl2", None),
+    "key_l1": ("single", "kl1", None), "value_l1": ("single", "vl1", None),
+    "value_l2_plus_key_l2": ("plus", "kl2", "vl2"), "value_l1_plus_key_l1": ("plus", "kl1", "vl1"),
+    "inverse_key_l2": ("inverse", "kl2", None), "inverse_key_l1": ("inverse", "kl1", None),
+    "key_l1_div_value_l1": ("div", "kl2", "vl1"), "key_l1_div_value_l2": ("div", "kl1", "vl2"),
+    "key_l2_div_value_l1": ("div", "kl2", "vl1"), "key_l2_div_value_l2": ("div", "kl2", "vl2"),
+    "value_l1_div_key_l1": ("div", "kl1", "vl1"), "value_l1_div_key_l2": ("div", "kl1", "vl2"),
+    "value_l2_div_key_l1": ("div", "kl2", "vl1"), "value_l2_div_key_l2": ("div", "kl2", "vl2"),
+    "cosine": ("cosine", None, None), "streamingLLM": ("position", None, None),
+}
+
+
+def readme_token_scores(keys: torch.Tensor, values: torch.Tensor, method: str) -> torch.Tensor:
+    """[T, H] scores of get_score (kvcache_prunner_old.py:77-134) in the input dtype.  Every
+    reduction runs in f32 in ascending element order and every operation's result is rounded to
+    the storage type where torch rounds it (after each norm, after ``+ 1e-8``, after the
+    division / sum; for the cosine after each quotient, each product and the final sum) - the
+    arithmetic the kernels use; torch's own vectorised sums may differ in the last f32 bit
+    before that rounding."""
+    import numpy as np
+    dt = keys.dtype
+    T, H, D = keys.shape
+    f32 = np.float32
+
+    def rt(a):       # round an f32 array to the storage type
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=f32)).to(dt).float().numpy()
+
+    def seq_sum(a):  # f32 sum over the last axis, one element after the other
+        return np.cumsum(a.astype(f32), axis=-1, dtype=f32)[..., -1]
+    k = keys.float().numpy().astype(f32)
+    v = values.float().numpy().astype(f32)
+    op, a, b = README_SCORES[method]
+    if op == "position":
+        return torch.arange(1, T + 1, dtype=torch.float32).view(-1, 1).expand(-1, H).to(dt)
+    if op == "cosine":
+        kn = np.maximum(rt(np.sqrt(seq_sum(k * k))), f32(1e-12))
+        vn = np.maximum(rt(np.sqrt(seq_sum(v * v))), f32(1e-12))
+        prod = rt(rt(k / kn[..., None]) * rt(v / vn[..., None]))
+        return torch.from_numpy(rt(seq_sum(prod))).to(dt)
+
+    def norm(which):
+        x = k if which[0] == "k" else v
+        return rt(seq_sum(np.abs(x))) if which.endswith("1") else rt(np.sqrt(seq_sum(x * x)))
+    na = norm(a)
+    with np.errstate(divide="ignore", invalid="ignore"):   # fp16: 0 + 1e-8 rounds to 0, 1/0 = inf as in torch
+        if op == "single":
+            out = na
+        elif op == "inverse":
+            out = rt(f32(1.0) / rt(na + f32(1e-8)))
+        elif op == "plus":
+            out = rt(na + norm(b))
+        else:
+            out = rt(na / rt(norm(b) + f32(1e-8)))
+    return torch.from_numpy(out).to(dt)
+
+
+def merge_keep_sets(values: torch.Tensor, n_keep: int, keys: Optional[torch.Tensor] = None,
+                    method: str = "value_l2") -> List[List[int]]:
     """Per head, the token indices that survive prune_oldest_block
     (kvcache_prunner_old.py:302-309): scores ||V[t, h, :]||_2 (sum of squares in ascending
-    element order, f32, rounded to the storage type), the T - n_keep lowest go, equal scores
-    lowest token first (torch.topk leaves that order unspecified)."""
+    element order, f32, rounded to the storage type) or, with ``keys`` and ``method``, any other
+    score of get_score; the T - n_keep lowest go, equal scores lowest token first (torch.topk
+    leaves that order unspecified)."""
     import numpy as np
     T, H, D = values.shape
+    if method != "value_l2":
+        score = readme_token_scores(keys, values, method).float()
+        order = torch.sort(score, dim=0, stable=True).indices
+        keep = torch.ones((T, H), dtype=torch.bool)
+        keep.scatter_(0, order[:T - n_keep], False)
+        return [keep[:, h].nonzero().flatten().tolist() for h in range(H)]
     sq = values.float().numpy().astype(np.float32)
     sq = sq * sq
     ss = np.cumsum(sq, axis=-1, dtype=np.float32)[..., -1]
@@ -533,7 +607,7 @@ def merge_keep_sets(values: torch.Tensor, n_keep: int) -> List[List[int]]:
 
 
 def merge_blocks_in_cache(key_cache: torch.Tensor, value_cache: torch.Tensor,
-                          block_ids: Sequence[int]) -> None:
+                          block_ids: Sequence[int], method: str = "value_l2") -> None:
     """The decode-time merge on the paged layouts (key_cache [nb, H, D/x, bs, x], value_cache
     [nb, H, D, bs]): logical rows of the listed blocks -> per-head selection -> the kept rows,
     in order, into block_ids[0] (the write-back of torch_cuda_sdpa.py:1350-1363).  Per-head
@@ -546,7 +620,7 @@ def merge_blocks_in_cache(key_cache: torch.Tensor, value_cache: torch.Tensor,
     # [n, H, D/x, bs, x] -> [n, bs, H, D]
     k = key_cache[ids].permute(0, 3, 1, 2, 4).reshape(len(ids) * bs, H, D)
     v = value_cache[ids].permute(0, 3, 1, 2).reshape(len(ids) * bs, H, D)
-    keep = merge_keep_sets(v, bs)
+    keep = merge_keep_sets(v, bs, k, method)
     for h in range(H):
         sel = torch.tensor(keep[h], dtype=torch.long)
         key_cache[ids[0], h] = k[sel, h].reshape(bs, Dx, x).permute(1, 0, 2)

@@ -155,6 +155,107 @@ def test_merge_blocks_golden_kept_sets(ops, oracle):
             assert torch.equal(got_v[:, h], v[keep[h], h]), (c, h)
 
 
+README_METHODS = ["cosine", "key_l1", "key_l2", "value_l1", "value_l2", "key_l1_div_value_l1",
+                  "key_l1_div_value_l2", "key_l2_div_value_l1", "key_l2_div_value_l2", "value_l1_div_key_l1",
+                  "value_l1_div_key_l2", "value_l2_div_key_l1", "value_l2_div_key_l2", "value_l1_plus_key_l1",
+                  "value_l2_plus_key_l2", "streamingLLM", "inverse_key_l1", "inverse_key_l2"]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+def test_readme_token_scores_vs_oracle_and_reference(ops, oracle, dtype):
+    """pe_token_scores for every method name of the README-era get_score
+    (kvcache_prunner_old.py:77-134): bit for bit the oracle's scores for 16-bit storage (same
+    arithmetic, same order), and within two representable values of what the reference class
+    itself returned (torch sums in another order; tests/golden/old_token_scores.npz)."""
+    g = torch.Generator().manual_seed(11)
+    T, H, D = 70, 3, 128
+    k = (torch.rand(T, H, D, generator=g) * 2 - 1).to(dtype)
+    v = (torch.rand(T, H, D, generator=g) * 4 - 2).to(dtype)
+    k[5] = 0                                              # a zero row: norms 0, cosine 0
+    for m in README_METHODS:
+        got = ops.token_scores(k.cuda(), v.cuda(), m).cpu()
+        want = oracle.readme_token_scores(k, v, m)
+        if dtype == torch.float32:
+            torch.testing.assert_close(got, want, rtol=2e-6, atol=1e-7)
+        else:
+            assert torch.equal(got, want), m
+    with pytest.raises(ValueError):
+        ops.token_scores(k.cuda(), v.cuda(), "key_l3")
+    code = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}[dtype]
+    z = np.load(os.path.join(GOLDEN, "old_token_scores.npz"))
+    seen = 0
+    for c in range(int(z["n_score_cases"])):
+        if int(z[f"s{c}_meta"][3]) != code:
+            continue
+        kk, vv = from_bits(z[f"s{c}_k"], code), from_bits(z[f"s{c}_v"], code)
+        for mi, m in enumerate(README_METHODS):
+            want = from_bits(z[f"s{c}_m{mi}"], 0 if m == "streamingLLM" else code)
+            got = ops.token_scores(kk.cuda(), vv.cuda(), m).cpu()
+            if m == "streamingLLM":
+                assert torch.equal(got.float(), want.float())
+            elif code == 0:
+                torch.testing.assert_close(got, want, rtol=2e-6, atol=1e-7)
+            else:
+                d = (got.view(torch.int16).int() - want.view(torch.int16).int()).abs()
+                assert int(d.max()) <= 2, (m, int(d.max()))
+            seen += 1
+    assert seen == 2 * len(README_METHODS)
+
+
+@pytest.mark.parametrize("method", ["cosine", "key_l1", "value_l1_div_key_l2", "value_l1_plus_key_l1",
+                                    "inverse_key_l1", "key_l2_div_value_l2", "value_l1"])
+def test_readme_scores_prompt_prune_and_merge(ops, oracle, method):
+    """The percentage type's prompt prune and decode merge under README-era scores: the pruner's
+    outputs against the oracle's (16-bit storage, scores that tie: lowest token first), the
+    reference's own outputs where the fixtures hold them (f32, its cross-head re-packing), and the
+    merge kernel against the oracle's merge on the paged layouts (negative scores included: the
+    cosine)."""
+    from vllm_paged_compression_amd.pruner import KVCachePruner
+    g = torch.Generator().manual_seed(len(method))
+    lens = [300, 40, 130, 97]
+    k = (torch.rand(sum(lens), 2, 64, generator=g) * 2 - 1).to(torch.bfloat16)
+    v = (torch.rand(sum(lens), 2, 64, generator=g) * 2 - 1).to(torch.bfloat16)
+    p = KVCachePruner("percentage", method, 16, 0, 1, evict_freq=2, decode_evict_method=method)
+    pk, pv, kept = p.prune_prompts_batch(k.cuda(), v.cuda(), lens)
+    off, ek, ev = 0, [], []
+    for L in lens:
+        a, b = oracle.percentage_prompt_prune(k[off:off + L], v[off:off + L], method, 16, 2)
+        ek.append(a)
+        ev.append(b)
+        off += L
+    assert kept == [t.shape[0] for t in ek]
+    assert torch.equal(pk.cpu(), torch.cat(ek)) and torch.equal(pv.cpu(), torch.cat(ev))
+    assert torch.equal(p.get_score(k[:50].cuda(), v[:50].cuda(), method).cpu(),
+                       oracle.readme_token_scores(k[:50], v[:50], method))
+    # the reference's own prune_prompt outputs (compat form)
+    z = np.load(os.path.join(GOLDEN, "old_token_scores.npz"))
+    for c in range(int(z["n_prune_cases"])):
+        L, freq, bs, nbm, H, D, mi = [int(x) for x in z[f"p{c}_meta"]]
+        if README_METHODS[mi] != method:
+            continue
+        kk, vv = from_bits(z[f"p{c}_k"], 0), from_bits(z[f"p{c}_v"], 0)
+        pc = KVCachePruner("percentage", method, bs, 0, 1, evict_freq=freq, num_block_merge=nbm,
+                           decode_evict_method="streamingLLM", cross_head_compat=True)
+        gk, gv = pc.prune_prompt(kk.cuda(), vv.cuda())
+        assert torch.equal(gk.cpu(), from_bits(z[f"p{c}_pk"], 0)), (c, method)
+        assert torch.equal(gv.cpu(), from_bits(z[f"p{c}_pv"], 0)), (c, method)
+    # decode merge on the paged layouts
+    for dtype, nbm, H, D, bs in ((torch.bfloat16, 2, 4, 128, 16), (torch.float16, 3, 2, 64, 16)):
+        B, M = 4, nbm + 3
+        nb = B * M + 2
+        x = 8
+        kc = ((torch.rand(nb, H, D // x, bs, x, generator=g) * 2 - 1)).to(dtype)
+        vc = ((torch.rand(nb, H, D, bs, generator=g) * 2 - 1)).to(dtype)
+        bt = torch.randperm(nb, generator=g)[:B * M].to(torch.int32).reshape(B, M)
+        rows = [1, 3]
+        kd, vd = kc.cuda(), vc.cuda()
+        ops.merge_blocks_value_l2(kd, vd, bt.cuda(), torch.tensor(rows, dtype=torch.int32).cuda(), 1, nbm,
+                                  formula=method)
+        for r in rows:
+            oracle.merge_blocks_in_cache(kc, vc, bt[r, 1:1 + nbm].tolist(), method)
+        assert torch.equal(kd.cpu(), kc) and torch.equal(vd.cpu(), vc), (method, dtype)
+
+
 def test_block_table_remove_range(ops, oracle):
     g = torch.Generator().manual_seed(1)
     bt = torch.randint(0, 1000, (7, 12), generator=g, dtype=torch.int32)
@@ -193,7 +294,8 @@ def _mk(T, Hq, Hkv, D, g):
     ("streamingLLM", 2, 2, False, "streamingLLM"), ("value_l2", 2, 2, False, "streamingLLM"),
     ("value_l2", 3, 1, False, "streamingLLM"), ("value_l2", 2, 2, True, "streamingLLM"),
     ("streamingLLM", 3, 2, True, "streamingLLM"), ("value_l2", 2, 2, False, "value_l2"),
-    ("value_l2", 2, 4, True, "inverse_key_l2")])
+    ("value_l2", 2, 4, True, "inverse_key_l2"), ("cosine", 2, 2, False, "key_l1"),
+    ("key_l2_div_value_l1", 3, 2, True, "value_l1_plus_key_l1"), ("inverse_key_l1", 2, 2, False, "cosine")])
 @pytest.mark.parametrize("disable_evict_prefill", [True, False])
 def test_backend_percentage_trace(oracle, decode_method, nbm, freq, batched, prompt_method,
                                   disable_evict_prefill):
@@ -316,7 +418,7 @@ def test_backend_percentage_trace(oracle, decode_method, nbm, freq, batched, pro
                                      torch.tensor(slots))
             for i, mg in enumerate(merged):
                 if mg is not None:
-                    oracle.merge_blocks_in_cache(kc_cpu[li], vc_cpu[li], tbls[i][mg[0]:mg[1]])
+                    oracle.merge_blocks_in_cache(kc_cpu[li], vc_cpu[li], tbls[i][mg[0]:mg[1]], decode_method)
             assert torch.equal(kv_gpu[li][0].view_as(kc_cpu[li]).cpu(), kc_cpu[li]), (step, li)
             assert torch.equal(kv_gpu[li][1].view_as(vc_cpu[li]).cpu(), vc_cpu[li]), (step, li)
             ref = oracle.paged_attention(q.view(3, Hq, D), kc_cpu[li], vc_cpu[li], use_tables,

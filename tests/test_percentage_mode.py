@@ -148,8 +148,11 @@ def test_config_percentage_validation():
         PagedEvictConfig(True, "percentage", "streamingLLM", 0, -1, evict_freq=2,
                          decode_evict_method="global")
     with pytest.raises(ValueError):
-        PagedEvictConfig(True, "percentage", "key_l1", 0, -1, evict_freq=2,
+        PagedEvictConfig(True, "percentage", "key_l3", 0, -1, evict_freq=2,
                          decode_evict_method="value_l2")
+    # every token score get_score of that era knows is a method name of either phase
+    c = PagedEvictConfig(True, "percentage", "key_l1", 0, -1, evict_freq=2, decode_evict_method="cosine")
+    assert (c.prompt_evict_method, c.decode_evict_method) == ("key_l1", "cosine")
     assert PagedEvictConfig(True, "percentage", "value_l2", 0, -1, evict_freq=2,
                             decode_evict_method="value_l2").prompt_evict_method == "value_l2"
 
@@ -197,3 +200,66 @@ def test_schedulers_percentage_commit(oracle, method, nbm):
             assert a.block_manager.get_seq_kv_len(i) == b.get_seq_kv_len(r)
     assert n_freed >= 6
     assert a.block_manager.get_num_free_gpu_blocks() == b.get_num_free_gpu_blocks()
+
+
+OLD_METHODS = ["cosine", "key_l1", "key_l2", "value_l1", "value_l2", "key_l1_div_value_l1",
+               "key_l1_div_value_l2", "key_l2_div_value_l1", "key_l2_div_value_l2", "value_l1_div_key_l1",
+               "value_l1_div_key_l2", "value_l2_div_key_l1", "value_l2_div_key_l2", "value_l1_plus_key_l1",
+               "value_l2_plus_key_l2", "streamingLLM", "inverse_key_l1", "inverse_key_l2"]
+
+
+def _ulp_apart(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """Distance in representable values of a 16-bit dtype (same sign assumed near equality)."""
+    ia, ib = a.view(torch.int16).to(torch.int32), b.view(torch.int16).to(torch.int32)
+    return (ia - ib).abs()
+
+
+def test_oracle_readme_token_scores_golden(oracle):
+    """The oracle's restatement of get_score (kvcache_prunner_old.py:77-134) against the
+    reference class's own outputs for every method name (tests/golden/make_golden_old_scores.py).
+    The oracle sums in f32 one element after the other (what the kernels do), torch vectorises
+    its sums: after rounding to a 16-bit type the two agree except where the f32 sums straddle a
+    rounding boundary - at most one representable value apart, on few entries; the divisions can
+    amplify that by one more.  f32 inputs: relative 2e-6."""
+    z = np.load(os.path.join(GOLDEN, "old_token_scores.npz"))
+    assert [str(m) for m in z["methods"]] == OLD_METHODS
+    assert sorted(oracle.README_SCORES) == sorted(OLD_METHODS)
+    checked = 0
+    for c in range(int(z["n_score_cases"])):
+        T, H, D, code = [int(x) for x in z[f"s{c}_meta"]]
+        k, v = from_bits(z[f"s{c}_k"], code), from_bits(z[f"s{c}_v"], code)
+        for mi, m in enumerate(OLD_METHODS):
+            want = from_bits(z[f"s{c}_m{mi}"], 0 if m == "streamingLLM" else code)
+            got = oracle.readme_token_scores(k, v, m)
+            if m == "streamingLLM":
+                assert torch.equal(got.float(), want.float())
+            elif code == 0:
+                torch.testing.assert_close(got, want, rtol=2e-6, atol=1e-7)
+            else:
+                d = _ulp_apart(got, want)
+                assert int(d.max()) <= 2, (m, code, int(d.max()))
+                assert float((d == 0).float().mean()) >= 0.9, (m, code)
+            checked += 1
+    assert checked == 6 * len(OLD_METHODS)
+
+
+def test_oracle_readme_prune_and_merge_golden(oracle):
+    """Prompt prune and decode merge under README-era scores against the reference's own
+    prune_prompt / prune_oldest_block (tie-free f32 inputs): the reference re-packs the kept
+    (token, head) rows across heads (compat form), so the kept rows are compared as it lays them
+    out; for the merge the kept key rows."""
+    z = np.load(os.path.join(GOLDEN, "old_token_scores.npz"))
+    for c in range(int(z["n_prune_cases"])):
+        L, freq, bs, nbm, H, D, mi = [int(x) for x in z[f"p{c}_meta"]]
+        k, v = from_bits(z[f"p{c}_k"], 0), from_bits(z[f"p{c}_v"], 0)
+        pk, pv = oracle.percentage_prompt_prune(k, v, OLD_METHODS[mi], bs, freq, 1, nbm, compat_q2=True)
+        assert torch.equal(pk, from_bits(z[f"p{c}_pk"], 0)), (c, OLD_METHODS[mi])
+        assert torch.equal(pv, from_bits(z[f"p{c}_pv"], 0)), (c, OLD_METHODS[mi])
+    for c in range(int(z["n_merge_cases"])):
+        nbm, bs, H, D, prune_tokens, mi = [int(x) for x in z[f"d{c}_meta"]]
+        k, v = from_bits(z[f"d{c}_k"], 0), from_bits(z[f"d{c}_v"], 0)
+        keep = oracle.merge_keep_sets(v, nbm * bs - prune_tokens, k, OLD_METHODS[mi])
+        mask = torch.zeros(nbm * bs, H, dtype=torch.bool)
+        for h in range(H):
+            mask[keep[h], h] = True
+        assert torch.equal(k[mask].view(-1, H, D), from_bits(z[f"d{c}_pk"], 0)), (c, OLD_METHODS[mi])

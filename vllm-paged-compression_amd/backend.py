@@ -1227,7 +1227,7 @@ class PagedEvictImpl(_ImplBase):
         if not trig_np.any():
             return dec
         dev = dm.block_tables.device
-        value_l2 = cfg.decode_evict_method == "value_l2"
+        value_l2 = cfg.decode_evict_method != "streamingLLM"     # a scored method: blocks are merged
         first_freed = ib + 1 if value_l2 else ib
         n_remove = nbm - 1
         M = dm.block_tables.shape[1]

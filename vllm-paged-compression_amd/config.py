@@ -15,8 +15,14 @@ logger = logging.getLogger(__name__)
 
 EVICT_METHODS = ("streamingLLM", "streamingLLM-1", "inverse_key_l2", "local", "global")
 # methods of the "percentage" prune type (README-era --prompt-evict-method / --decode-evict-method)
-PERCENTAGE_PROMPT_METHODS = ("streamingLLM", "value_l2", "inverse_key_l2")
-PERCENTAGE_DECODE_METHODS = ("streamingLLM", "value_l2")
+# token scores get_score of the README-era pruner knows (vllm/attention/kvcache_prunner_old.py:77-134)
+TOKEN_SCORE_METHODS = ("cosine", "key_l1", "key_l2", "value_l1", "value_l2", "key_l1_div_value_l1",
+                       "key_l1_div_value_l2", "key_l2_div_value_l1", "key_l2_div_value_l2",
+                       "value_l1_div_key_l1", "value_l1_div_key_l2", "value_l2_div_key_l1",
+                       "value_l2_div_key_l2", "value_l1_plus_key_l1", "value_l2_plus_key_l2",
+                       "inverse_key_l1", "inverse_key_l2")
+PERCENTAGE_PROMPT_METHODS = ("streamingLLM",) + TOKEN_SCORE_METHODS
+PERCENTAGE_DECODE_METHODS = ("streamingLLM",) + TOKEN_SCORE_METHODS
 
 
 class PagedEvictConfig:
@@ -36,8 +42,8 @@ class PagedEvictConfig:
                            (whole blocks) and a decode step prunes every evict_freq blocks
     num_block_merge:       blocks a decode prune works on: num_block_merge-1 of them are freed
     prompt_evict_method / decode_evict_method: the two method flags of that era
-                           (prompt: "streamingLLM", "value_l2", "inverse_key_l2"; decode:
-                           "streamingLLM", "value_l2"); default evict_method
+                           ("streamingLLM" or a token score of TOKEN_SCORE_METHODS, the
+                           names get_score of that era's pruner knows); default evict_method
     """
 
     def __init__(self, disable_evict_prefill: bool, cache_prune_type: str, evict_method: str,

@@ -25,6 +25,14 @@ EVICT_METHODS = {"streamingLLM": 0, "streamingLLM-1": 1, "local": 2, "global": 3
 SCORE_TOKEN_MAJOR, SCORE_CACHE, SCORE_CACHE_FLAT, SCORE_KEY_CACHE = 0, 1, 2, 3
 # KVCachePruner.sub_evict_method (kvcache_prunner.py:13,29-66) -> pe_score_formula
 SCORE_FORMULAS = {"value_l2": 0, "key_l2": 1, "value_l2_plus_key_l2": 2, "inverse_key_l2": 3}
+# token scores of the README-era class, by its method names (get_score,
+# vllm/attention/kvcache_prunner_old.py:77-134) -> pe_score_formula; "streamingLLM" as a score is
+# the token's position
+TOKEN_SCORE_FORMULAS = dict(SCORE_FORMULAS, key_l1=4, value_l1=5, inverse_key_l1=6,
+                            key_l1_div_value_l1=7, key_l1_div_value_l2=8, key_l2_div_value_l1=9,
+                            key_l2_div_value_l2=10, value_l1_div_key_l1=11, value_l1_div_key_l2=12,
+                            value_l2_div_key_l1=13, value_l2_div_key_l2=14, value_l1_plus_key_l1=15,
+                            cosine=16, streamingLLM=17)
 _SCORE_FORMULA_SHIFT = 8
 
 
@@ -406,7 +414,7 @@ def prompt_token_select(key: torch.Tensor, value: torch.Tensor, cu_q: torch.Tens
     of a prompt is its length minus its kept length).  ``formula``: the score of "local" /
     "global" (SCORE_FORMULAS; "inverse_key_l2" as a method always uses its own)."""
     dev = _need_gpu(key, value, cu_q, cu_kept)
-    if formula not in SCORE_FORMULAS:
+    if formula not in TOKEN_SCORE_FORMULAS:
         raise ValueError(f"Unknown score formula: {formula}")
     T, H, D = key.shape
     idx = torch.empty((total_kept, H), dtype=torch.int32, device=dev)
@@ -415,7 +423,7 @@ def prompt_token_select(key: torch.Tensor, value: torch.Tensor, cu_q: torch.Tens
     ws = _workspace(dev, need, "select")
     _lib.check(lib.pe_prompt_token_select(
         _p(idx), _p(key), _p(value), _p(cu_q), _p(cu_kept), cu_q.numel() - 1, T, cache_budget,
-        block_size, EVICT_METHODS[method] | (SCORE_FORMULAS[formula] << _SCORE_FORMULA_SHIFT),
+        block_size, EVICT_METHODS[method] | (TOKEN_SCORE_FORMULAS[formula] << _SCORE_FORMULA_SHIFT),
         1 if compat_q2 else 0, tail_blocks, key.stride(0),
         value.stride(0),
         H, D, _dtype_code(key), _p(ws), 0 if ws is None else ws.numel(), _stream(dev)),
@@ -653,13 +661,33 @@ def evict_select_compact_inplace(block_tables: torch.Tensor, num_blocks: torch.T
     return rmv, freed, zero
 
 
+def token_scores(key: torch.Tensor, value: torch.Tensor, formula: str) -> torch.Tensor:
+    """get_score of the README-era class (vllm/attention/kvcache_prunner_old.py:77-134) on dense
+    [T, H, D] key / value tensors: [T, H] scores in the tensors' dtype."""
+    dev = _need_gpu(key, value)
+    if formula not in TOKEN_SCORE_FORMULAS:
+        raise ValueError(f"Unknown score formula: {formula}")
+    T, H, D = key.shape
+    if value.shape != key.shape or key.stride(2) != 1 or value.stride(2) != 1 \
+            or key.stride(1) != D or value.stride(1) != D:
+        raise RuntimeError("token_scores: dense [tokens, heads, head_size] rows expected")
+    out = torch.empty((T, H), dtype=torch.float32, device=dev)
+    _lib.check(_lib.load().pe_token_scores(_p(out), _p(key), _p(value), T, key.stride(0), value.stride(0),
+                                           H, D, TOKEN_SCORE_FORMULAS[formula], _dtype_code(key),
+                                           _stream(dev)), "token_scores")
+    return out.to(key.dtype)
+
+
 def merge_blocks_value_l2(key_cache: torch.Tensor, value_cache: torch.Tensor,
                           block_tables: torch.Tensor, rows: torch.Tensor, first_block: int,
-                          num_block_merge: int) -> None:
+                          num_block_merge: int, formula: str = "value_l2") -> None:
     """In place, for every batch row listed in ``rows`` (int32) and every KV head: merge the
     ``num_block_merge`` blocks from table column ``first_block`` into the first of them, keeping
-    the block_size tokens with the highest ||V||_2 in their original order (the decode-time
-    merge of the percentage prune type, kvcache_prunner_old.py:264-315)."""
+    the block_size tokens with the highest score (``formula``: ||V||_2 by default, or any method
+    name get_score knows) in their original order (the decode-time merge of the percentage prune
+    type, kvcache_prunner_old.py:264-315)."""
+    if formula not in TOKEN_SCORE_FORMULAS:
+        raise ValueError(f"Unknown score formula: {formula}")
     dev = _need_gpu(key_cache, value_cache, block_tables, rows)
     nb, Hkv, D, bs = value_cache.shape
     if key_cache.dtype != value_cache.dtype or key_cache.shape[0] != nb or key_cache.shape[1] != Hkv:
@@ -671,10 +699,11 @@ def merge_blocks_value_l2(key_cache: torch.Tensor, value_cache: torch.Tensor,
         if t.dtype != torch.int32 or not t.is_contiguous():
             raise RuntimeError("merge_blocks_value_l2: int32 contiguous tensors expected")
     lib = _lib.load()
-    _lib.check(lib.pe_merge_blocks_value_l2(
+    _lib.check(lib.pe_merge_blocks_scored(
         _p(key_cache), _p(value_cache), _p(block_tables), _p(rows), rows.numel(),
         block_tables.shape[1], first_block, num_block_merge, Hkv, D, bs, value_cache.stride(0),
-        value_cache.stride(1), _dtype_code(value_cache), _stream(dev)), "merge_blocks_value_l2")
+        value_cache.stride(1), TOKEN_SCORE_FORMULAS[formula], _dtype_code(value_cache), _stream(dev)),
+        "merge_blocks_scored")
 
 
 def block_table_remove_range(block_tables: torch.Tensor, start: torch.Tensor, n_remove: int,

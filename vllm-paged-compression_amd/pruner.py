@@ -44,9 +44,9 @@ class KVCachePruner:
         if cache_prune_type == "percentage":
             assert evict_freq is not None and evict_freq >= 1 and num_block_merge >= 2
             assert initial_blocks == 1, "the kept-row index jumps after the first block"
-            if evict_method not in ("streamingLLM", "value_l2", "inverse_key_l2"):
+            if evict_method not in ops.TOKEN_SCORE_FORMULAS:
                 raise ValueError(f"Unknown prompt eviction method for the percentage type: {evict_method}")
-            if self.decode_evict_method not in ("streamingLLM", "value_l2"):
+            if self.decode_evict_method not in ops.TOKEN_SCORE_FORMULAS:
                 raise ValueError("Unknown decode eviction method for the percentage type: "
                                  f"{self.decode_evict_method}")
             return
@@ -91,12 +91,19 @@ class KVCachePruner:
 
     def merge_blocks_in_cache(self, key_cache: torch.Tensor, value_cache: torch.Tensor,
                               block_tables: torch.Tensor, rows: torch.Tensor) -> None:
-        """value_l2 decode prune for the batch rows listed in ``rows``: per KV head the
-        block_size highest-||V|| tokens of the merged blocks survive, in order, in the first of
-        them (prune_oldest_block + write-back, kvcache_prunner_old.py:297-315 and
-        torch_cuda_sdpa.py:1331-1363, in place on the paged cache)."""
+        """Scored decode prune (value_l2 or any other token score of get_score) for the batch rows
+        listed in ``rows``: per KV head the block_size highest-score tokens of the merged blocks
+        survive, in order, in the first of them (prune_oldest_block + write-back,
+        kvcache_prunner_old.py:297-315 and torch_cuda_sdpa.py:1331-1363, in place on the paged
+        cache)."""
         s, _, _ = self.get_blocks_to_prune_and_merge_decode(0)
-        ops.merge_blocks_value_l2(key_cache, value_cache, block_tables, rows, s, self.num_block_merge)
+        ops.merge_blocks_value_l2(key_cache, value_cache, block_tables, rows, s, self.num_block_merge,
+                                  formula=self.decode_evict_method)
+
+    def get_score(self, block_keys: torch.Tensor, block_values: torch.Tensor, evict_method: str):
+        """[T, H] token scores of dense [T, H, D] rows under any method name of the README-era
+        class (get_score, kvcache_prunner_old.py:77-134)."""
+        return ops.token_scores(block_keys.contiguous(), block_values.contiguous(), evict_method)
 
     # ------------------------------------------------------------------ device index
     def keep_index(self, key: torch.Tensor, value: torch.Tensor, seq_lens: Sequence[int],
@@ -114,11 +121,10 @@ class KVCachePruner:
         total = sum(kept)
         if self.cache_prune_type == "percentage" and self.evict_method != "streamingLLM":
             # token-level scores of that era (kvcache_prunner_old.py:201-262): per head the
-            # lowest-score middle tokens go; "value_l2" is the score the budget type calls "global"
-            method = "global" if self.evict_method == "value_l2" else self.evict_method
+            # lowest-score middle tokens go, under the score the method names
             idx = ops.prompt_token_select(key, value, cu_q, cu_kept, total, 0, self.orig_block_size,
-                                          method, compat_q2=self.cross_head_compat,
-                                          tail_blocks=self.num_block_merge)
+                                          "global", compat_q2=self.cross_head_compat,
+                                          tail_blocks=self.num_block_merge, formula=self.evict_method)
         elif self.cache_prune_type == "percentage":
             # budget 0: the pruned count of each prompt is its length minus its kept length
             idx = ops.prompt_keep_index_streaming(cu_q, cu_kept, total, 0, self.orig_block_size)
