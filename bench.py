@@ -314,6 +314,9 @@ class Workload:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.stream(side):
             with torch.cuda.graph(graph, stream=side):
+                # the step's table append is the graph's first node: it reads the step's entries
+                # from the scheduler's pinned ring, so a replay is the only submission of a step
+                self._dev_state.launch_advance()
                 for li, impl in enumerate(self.impls):
                     impl.forward(self.qd, self.kd, self.vd, self.kv[li], meta)
         torch.cuda.current_stream().wait_stream(side)
@@ -369,6 +372,8 @@ class Workload:
                                        device=None if (a.host_tables or a.reference_head_compat)
                                        else self.dev, device_state=self._dev_state)
         self._dev_state = sched.device_state
+        if self.use_graph:
+            self._dev_state.defer_advance = True      # issued below: eagerly, or by the step's graph
         rids = [f"req{i}" for i in range(B)]
         for i, r in enumerate(rids):
             sched.add_request(r, i, L0)
@@ -433,6 +438,8 @@ class Workload:
                 rmv = staging.AsyncReadback(rmv_dev[:B]).tolist()
                 sched.commit({i: (rids[i], r) for i, r in enumerate(rmv) if r >= 0})
             else:
+                if use_graph:
+                    self._dev_state.launch_advance()
                 self._layers(self.qd, self.kd, self.vd, meta, self.o_partial_d, decode_bytes=nbytes,
                              positions=None if self.cos_sin is None else self.pos_d)
                 if plain:

@@ -465,6 +465,14 @@ int pe_evict_select_compact(int32_t* rmv_idx_out, int32_t* out_tables,
  *   removes a block; 2: percentage type, (num_block_merge-1)*block_size tokens when
  *   seq_len % (block_size*evict_freq) == 0 and kv_len > (initial_blocks+num_block_merge)*block_size).
  *   last_blocks_out (optional) = id of each row's last block (what a head-sharded caller scores).
+ * pe_table_state_advance_ring: the same step with the per-sequence entries taken from a ring of
+ *   rows, new_blocks_ring int32 [ring_len, ring_stride]: sequence b reads row
+ *   (seq_lens[b] + 1) % ring_len - its logical length after the step - so the launch has the same
+ *   arguments at every step and can be a node of a replayed HIP graph.  The ring may be pinned
+ *   host memory mapped into the device (then nothing is copied per step: the host stores the
+ *   step's entries, -1 where no block was allocated, before it submits the launch).  The caller
+ *   keeps the host fewer than ring_len steps ahead of the device and lets the pending launches
+ *   drain before it gives a batch slot to another sequence.
  * pe_evict_select_compact_inplace: pe_evict_select_compact on that state - the victim's column
  *   is closed inside the row (no second table), num_blocks[b] and kv_lens[b] are updated, and
  *   freed_blocks_out[b] = the victim's block id (-1: none) for the host's free list.  Victim
@@ -477,6 +485,13 @@ int pe_table_state_advance(int32_t* tables, int32_t* num_blocks, int32_t* kv_len
                            int32_t* last_blocks_out, int evict_rule, int cache_budget,
                            int block_size, int evict_freq, int num_block_merge, int initial_blocks,
                            void* stream);
+int pe_table_state_advance_ring(int32_t* tables, int32_t* num_blocks, int32_t* kv_lens,
+                                int32_t* seq_lens, const int32_t* new_blocks_ring, int ring_len,
+                                int64_t ring_stride, int batch, int max_blocks,
+                                int64_t* slot_mapping_out, int32_t* attn_kv_lens_out,
+                                int32_t* last_blocks_out, int evict_rule, int cache_budget,
+                                int block_size, int evict_freq, int num_block_merge,
+                                int initial_blocks, void* stream);
 int pe_evict_select_compact_inplace(int32_t* rmv_idx_out, int32_t* freed_blocks_out,
                                     int64_t* zero_slots_out, int32_t* block_tables,
                                     int32_t* num_blocks, int32_t* kv_lens, const int32_t* seq_lens,

@@ -198,3 +198,104 @@ def test_device_rows_follow_a_request_id_that_returns():
     table = sched.get_block_table("r")
     assert int(st.slot_mapping[0]) == table[100 // BS] * BS + 100 % BS
     ops.check_device_diagnostics()
+
+
+def test_table_state_advance_ring_form():
+    """pe_table_state_advance_ring: sequence b takes the step's entry from the ring row its new
+    logical length selects (pinned host memory read in place, or a device ring); many steps queued
+    back to back, checked against the plain form fed step by step."""
+    from vllm_paged_compression_amd import ops
+    rng = np.random.default_rng(9)
+    B, M, R, steps = 21, 40, 8, 6
+    dev = torch.device("cuda:0")
+    n_blocks = rng.integers(3, 6, B)
+    kv = np.array([rng.integers((n - 1) * BS + 1, n * BS + 1) for n in n_blocks])
+    L = kv + rng.integers(0, 100, B)
+    tables = np.zeros((B, M), dtype=np.int32)
+    for b in range(B):
+        tables[b, :n_blocks[b]] = rng.permutation(500)[:n_blocks[b]] + 1
+    t = lambda a, dt=torch.int32: torch.tensor(np.asarray(a), dtype=dt, device=dev)  # noqa: E731
+    per_step, kv_h, n_h, nxt = [], kv.copy(), n_blocks.copy(), 1000
+    for s in range(steps):
+        nb = np.full(B, -1, dtype=np.int32)
+        for b in range(B):
+            if kv_h[b] == n_h[b] * BS:
+                nb[b] = nxt
+                nxt += 1
+                n_h[b] += 1
+        kv_h += 1
+        per_step.append(nb)
+
+    def run(ring_tensor):
+        st = [t(tables), t(n_blocks), t(kv), t(L)]
+        slots = torch.empty(B, dtype=torch.int64, device=dev)
+        attn = torch.empty(B, dtype=torch.int32, device=dev)
+        seen = []
+        for s in range(steps):
+            if ring_tensor is None:
+                ops.table_state_advance(*st, t(per_step[s]), B, slots, attn, None, 1, 64, BS)
+            else:
+                ops.table_state_advance(*st, ring_tensor, B, slots, attn, None, 1, 64, BS)
+            seen.append((slots.clone(), attn.clone()))
+        return [x.cpu() for x in st], [(a.cpu(), b.cpu()) for a, b in seen]
+
+    ring = np.full((R, B + 3), -1, dtype=np.int32)
+    for s in range(steps):                      # all steps stored up front: steps < R
+        ring[(L + 1 + s) % R, np.arange(B)] = per_step[s]
+    want = run(None)
+    for ring_tensor in (torch.from_numpy(ring).pin_memory(), torch.from_numpy(ring).to(dev)):
+        got = run(ring_tensor)
+        for x, y in zip(want[0], got[0]):
+            assert torch.equal(x, y)
+        for (a, b), (c, d) in zip(want[1], got[1]):
+            assert torch.equal(a, c) and torch.equal(b, d)
+    assert sum(int((p >= 0).sum()) for p in per_step) >= 3
+    with pytest.raises(RuntimeError):           # a pageable host ring is refused
+        run(torch.from_numpy(ring))
+    ops.check_device_diagnostics()
+
+
+def test_deferred_advance_in_a_replayed_graph():
+    """defer_advance: schedule_decode only stores the step's entries in the pinned ring and the
+    launch is the first node of a HIP graph replayed once per step, far more steps than the ring
+    has rows; state and slot mappings equal those of the scheduler that launches every step
+    itself."""
+    from vllm_paged_compression_amd import ops
+    from vllm_paged_compression_amd.batch_scheduler import BatchEvictionScheduler, DeviceTableState
+    from vllm_paged_compression_amd.config import PagedEvictConfig
+    dev = torch.device("cuda:0")
+    cfg = PagedEvictConfig(True, "budget", "streamingLLM", 64, 3)
+    steps = 3 * DeviceTableState.RING + 5
+    res = []
+    for deferred in (False, True):
+        sched = BatchEvictionScheduler(BS, 400, cfg, max_seqs=4, max_blocks_per_seq=32, device=dev)
+        rids = ["a", "b", "c"]
+        for i, r in enumerate(rids):
+            sched.add_request(r, i, 50 + 7 * i)
+        st = sched.device_state
+        st.defer_advance = deferred
+        graph, slots = None, []
+        for s in range(steps):
+            sched.schedule_decode(rids)
+            if deferred:
+                if graph is None:
+                    st.launch_advance()           # eager first step (warm-up), then capture
+                    graph = torch.cuda.CUDAGraph()
+                    side = torch.cuda.Stream()
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side), torch.cuda.graph(graph, stream=side):
+                        st.launch_advance()
+                    torch.cuda.current_stream().wait_stream(side)
+                else:
+                    graph.replay()
+            rmv, freed, _ = ops.evict_select_compact_inplace(st.tables, st.num_blocks, st.kv_lens, st.seq_lens,
+                                                             3, "streamingLLM", 64, BS)
+            slots.append(st.slot_mapping[:3].clone())
+            rl = rmv.cpu().tolist()               # (a real engine reads the victims back like this)
+            sched.commit({i: (rids[i], r) for i, r in enumerate(rl) if r >= 0})
+        n = st.num_blocks[:3].cpu().tolist()
+        assert [st.tables[i, :n[i]].cpu().tolist() for i in range(3)] == [sched.get_block_table(r) for r in rids]
+        res.append((torch.stack(slots).cpu(), st.kv_lens[:3].cpu(), st.seq_lens[:3].cpu()))
+    for x, y in zip(*res):
+        assert torch.equal(x, y)
+    ops.check_device_diagnostics()

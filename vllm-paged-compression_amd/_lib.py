@@ -65,6 +65,9 @@ SIGNATURES = {
     "pe_table_state_advance": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                        c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                        c_int, c_void_p]),
+    "pe_table_state_advance_ring": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64,
+                                            c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                            c_int, c_int, c_int, c_void_p]),
     "pe_evict_select_compact_inplace": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                 c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                                 c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,

@@ -52,7 +52,17 @@ class DeviceTableState:
     int32 per sequence - the id of a block allocated for it this step, or -1 - and the device
     appends it, advances both length counters and derives the step's slot mapping and the kv
     lengths attention must see (``advance``, one launch).  The eviction launch of the step then
-    closes the victim's column inside the row.  ``h2d_bytes`` counts what crossed PCIe."""
+    closes the victim's column inside the row.  ``h2d_bytes`` counts what crossed PCIe.
+
+    The per-step entries go through a ring of pinned host rows that the launch reads in place
+    (sequence b's entry sits in the row its new logical length selects, so the launch has the same
+    arguments at every step): no copy is queued, and the launch can be a node of a replayed HIP
+    graph.  With ``defer_advance`` set, ``advance`` only stores the step's entries and the engine
+    issues the launch itself - ``launch_advance()``, eagerly or captured at the head of the
+    step's graph."""
+
+    RING = 64      # steps the host may run ahead of the device, kept below this by events
+    _GUARD = 16    # an event every so many steps
 
     def __init__(self, capacity: int, max_blocks: int, device):
         import torch
@@ -69,14 +79,27 @@ class DeviceTableState:
         self.loads = 0
         self.score_rows = None       # device int32 [batch] cached by the backend per batch key
         self.score_rows_key = None
+        self.ring = torch.full((self.RING, capacity), -1, dtype=torch.int32).pin_memory()
+        self._ring_np = self.ring.numpy()
+        self._cols = np.arange(capacity)
+        self._steps = 0
+        self._events: Dict[int, "torch.cuda.Event"] = {}
+        self._advance_args = None
+        self.defer_advance = False
 
     def load(self, key, tables: np.ndarray, n_blocks: np.ndarray, kv_lens: np.ndarray,
              seq_lens: np.ndarray) -> None:
         """(Re)load rows 0..B-1 from host arrays: the batch composition changed."""
+        import torch
         from . import staging
         B, m = tables.shape
         if B > self.capacity or m > self.max_blocks:
             raise RuntimeError("DeviceTableState: batch or table wider than the device state")
+        if self._steps:
+            # launches still queued read ring entries of the rows' previous owners
+            torch.cuda.current_stream(self.device).synchronize()
+            self._events.clear()
+            self._steps = 0
         t, nb, kv, sl = staging.upload([np.ascontiguousarray(tables, dtype=np.int32),
                                         n_blocks.astype(np.int32), kv_lens.astype(np.int32),
                                         seq_lens.astype(np.int32)], self.device)
@@ -90,15 +113,36 @@ class DeviceTableState:
         self.seq_lens[:B].copy_(sl)
         self.batch, self.key = B, key
 
-    def advance(self, new_blocks: np.ndarray, evict_rule: int, cache_budget: int, block_size: int,
-                evict_freq: int = 0, num_block_merge: int = 2, initial_blocks: int = 1) -> None:
-        from . import ops, staging
-        nb = staging.upload_i32(new_blocks, self.device)
-        self.h2d_bytes += 4 * len(new_blocks)
-        ops.table_state_advance(self.tables, self.num_blocks, self.kv_lens, self.seq_lens, nb,
+    def advance(self, new_blocks: np.ndarray, logical_lens: np.ndarray, evict_rule: int,
+                cache_budget: int, block_size: int, evict_freq: int = 0, num_block_merge: int = 2,
+                initial_blocks: int = 1) -> None:
+        """``logical_lens``: the sequences' logical lengths with this step's token (what the
+        device's counters will read after the step)."""
+        import torch
+        B = len(new_blocks)
+        t = self._steps
+        if t % self._GUARD == 0:
+            # everything submitted so far covers the launches of the steps before this one
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self._events[t] = ev
+            old = self._events.pop(t - 2 * self._GUARD, None)
+            if old is not None:
+                old.synchronize()     # the device is at most RING - _GUARD steps behind the host
+        self._steps = t + 1
+        self._ring_np[np.asarray(logical_lens) % self.RING, self._cols[:B]] = new_blocks
+        self.h2d_bytes += 4 * B
+        self._advance_args = (evict_rule, cache_budget, block_size, evict_freq, num_block_merge,
+                              initial_blocks)
+        if not self.defer_advance:
+            self.launch_advance()
+
+    def launch_advance(self) -> None:
+        """The step's launch on the current stream (or into the graph being captured)."""
+        from . import ops
+        ops.table_state_advance(self.tables, self.num_blocks, self.kv_lens, self.seq_lens, self.ring,
                                 self.batch, self.slot_mapping, self.attn_kv_lens, self.last_blocks,
-                                evict_rule, cache_budget, block_size, evict_freq, num_block_merge,
-                                initial_blocks)
+                                *self._advance_args)
 
 
 class BatchEvictionScheduler:
@@ -120,6 +164,7 @@ class BatchEvictionScheduler:
                 # buffers); whatever it holds belongs to nobody any more
                 device_state.key = device_state.score_rows_key = None
                 device_state.batch = 0
+                device_state.defer_advance = False
                 self.device_state = device_state
             else:
                 self.device_state = DeviceTableState(max_seqs, max_blocks_per_seq, device)
@@ -255,13 +300,15 @@ class BatchEvictionScheduler:
             cfg = self.paged_evict_config
             if cfg is not None and cfg.cache_prune_type == "percentage":
                 # num_block_merge-1 blocks leave every evict_freq blocks (percentage_decode_trigger)
-                st.advance(new_blocks, 2, 0, bs, cfg.evict_freq, cfg.num_block_merge, cfg.initial_blocks)
+                st.advance(new_blocks, self.num_full[rows], 2, 0, bs, cfg.evict_freq, cfg.num_block_merge,
+                           cfg.initial_blocks)
             else:
                 rule = 0
                 if cfg is not None and cfg.evict_method in ("streamingLLM", "streamingLLM-1", "global",
                                                             "local"):
                     rule = 1
-                st.advance(new_blocks, rule, cfg.cache_budget if cfg is not None else 0, bs)
+                st.advance(new_blocks, self.num_full[rows], rule,
+                           cfg.cache_budget if cfg is not None else 0, bs)
             return DecodeBatch(list(request_ids), self._batch_seq_ids, rows, None, lens.copy(),
                                self.num_cached[rows], self.num_full[rows], device_state=st,
                                host_tables=self.tables)

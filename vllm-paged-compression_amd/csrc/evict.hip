@@ -817,14 +817,16 @@ __global__ void table_state_advance_kernel(
     int32_t* __restrict__ seq_lens, const int32_t* __restrict__ new_blocks, int batch,
     int max_blocks, int64_t* __restrict__ slot_mapping_out, int32_t* __restrict__ attn_kv_lens_out,
     int32_t* __restrict__ last_blocks_out, int rule, int cache_budget, int block_size,
-    int evict_freq, int num_block_merge, int initial_blocks) {
+    int evict_freq, int num_block_merge, int initial_blocks, int ring_len, int64_t ring_stride) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= batch) return;
   int32_t* row = tables + (int64_t)b * max_blocks;
   int nb = n_blocks[b];
   const int kv = kv_lens[b] + 1;   // physical length with this step's token
   const int L = seq_lens[b] + 1;   // logical length with this step's token
-  const int nblk_new = new_blocks[b];
+  // ring form: the step's entry of sequence b sits in the ring row its new logical length selects,
+  // so the same launch (a node of a replayed graph) finds a new row at every step
+  const int nblk_new = new_blocks[(ring_len > 1 ? (int64_t)(L % ring_len) * ring_stride : 0) + b];
   bool bad = false;
   if (nblk_new >= 0) {
     if (nb < max_blocks) {
@@ -868,12 +870,13 @@ int state_diag_fetch(unsigned int* out, int reset) {
 
 extern "C" {
 
-int pe_table_state_advance(int32_t* tables, int32_t* num_blocks, int32_t* kv_lens,
-                           int32_t* seq_lens, const int32_t* new_blocks, int batch, int max_blocks,
-                           int64_t* slot_mapping_out, int32_t* attn_kv_lens_out,
-                           int32_t* last_blocks_out, int evict_rule, int cache_budget,
-                           int block_size, int evict_freq, int num_block_merge, int initial_blocks,
-                           void* stream) {
+static int table_state_advance_impl(int32_t* tables, int32_t* num_blocks, int32_t* kv_lens,
+                                    int32_t* seq_lens, const int32_t* new_blocks, int ring_len,
+                                    int64_t ring_stride, int batch, int max_blocks,
+                                    int64_t* slot_mapping_out, int32_t* attn_kv_lens_out,
+                                    int32_t* last_blocks_out, int evict_rule, int cache_budget,
+                                    int block_size, int evict_freq, int num_block_merge,
+                                    int initial_blocks, void* stream) {
   using namespace pe;
   PE_REQUIRE(batch >= 0, PE_ERR_INVALID_ARG, "negative batch");
   if (batch == 0) return PE_OK;
@@ -884,12 +887,41 @@ int pe_table_state_advance(int32_t* tables, int32_t* num_blocks, int32_t* kv_len
              PE_ERR_INVALID_ARG, "table_state_advance: bad sizes");
   PE_REQUIRE(evict_rule != 2 || (evict_freq > 0 && num_block_merge >= 2), PE_ERR_INVALID_ARG,
              "table_state_advance: percentage rule needs evict_freq and num_block_merge");
+  PE_REQUIRE(ring_len >= 1 && (ring_len == 1 || ring_stride >= batch), PE_ERR_INVALID_ARG,
+             "table_state_advance: ring rows shorter than the batch");
   hipLaunchKernelGGL(table_state_advance_kernel, dim3((unsigned)((batch + 127) / 128)), dim3(128), 0,
                      static_cast<hipStream_t>(stream), tables, num_blocks, kv_lens, seq_lens,
                      new_blocks, batch, max_blocks, slot_mapping_out, attn_kv_lens_out,
                      last_blocks_out, evict_rule, cache_budget, block_size, evict_freq,
-                     num_block_merge, initial_blocks);
+                     num_block_merge, initial_blocks, ring_len, ring_stride);
   return check_launch("table_state_advance");
+}
+
+int pe_table_state_advance(int32_t* tables, int32_t* num_blocks, int32_t* kv_lens,
+                           int32_t* seq_lens, const int32_t* new_blocks, int batch, int max_blocks,
+                           int64_t* slot_mapping_out, int32_t* attn_kv_lens_out,
+                           int32_t* last_blocks_out, int evict_rule, int cache_budget,
+                           int block_size, int evict_freq, int num_block_merge, int initial_blocks,
+                           void* stream) {
+  return table_state_advance_impl(tables, num_blocks, kv_lens, seq_lens, new_blocks, 1, 0, batch,
+                                  max_blocks, slot_mapping_out, attn_kv_lens_out, last_blocks_out,
+                                  evict_rule, cache_budget, block_size, evict_freq, num_block_merge,
+                                  initial_blocks, stream);
+}
+
+int pe_table_state_advance_ring(int32_t* tables, int32_t* num_blocks, int32_t* kv_lens,
+                                int32_t* seq_lens, const int32_t* new_blocks_ring, int ring_len,
+                                int64_t ring_stride, int batch, int max_blocks,
+                                int64_t* slot_mapping_out, int32_t* attn_kv_lens_out,
+                                int32_t* last_blocks_out, int evict_rule, int cache_budget,
+                                int block_size, int evict_freq, int num_block_merge,
+                                int initial_blocks, void* stream) {
+  using namespace pe;
+  PE_REQUIRE(ring_len >= 2, PE_ERR_INVALID_ARG, "table_state_advance_ring: a ring has at least 2 rows");
+  return table_state_advance_impl(tables, num_blocks, kv_lens, seq_lens, new_blocks_ring, ring_len,
+                                  ring_stride, batch, max_blocks, slot_mapping_out, attn_kv_lens_out,
+                                  last_blocks_out, evict_rule, cache_budget, block_size, evict_freq,
+                                  num_block_merge, initial_blocks, stream);
 }
 
 }  // extern "C"

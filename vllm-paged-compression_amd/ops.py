@@ -587,19 +587,34 @@ def table_state_advance(tables: torch.Tensor, num_blocks: torch.Tensor, kv_lens:
                         block_size: int, evict_freq: int = 0, num_block_merge: int = 2,
                         initial_blocks: int = 1) -> None:
     """One decode step's append on device-resident tables (see pe_table_state_advance): rows
-    0..batch-1 of the state arrays are the step's sequences in batch order."""
-    dev = _need_gpu(tables, num_blocks, kv_lens, seq_lens, new_blocks, slot_mapping_out,
-                    attn_kv_lens_out, last_blocks_out)
+    0..batch-1 of the state arrays are the step's sequences in batch order.  A two-dimensional
+    ``new_blocks`` [ring_len, >= batch] is a ring of per-step rows (pe_table_state_advance_ring):
+    sequence b takes its entry from row (seq_lens[b] + 1) % ring_len; it may be a pinned host
+    tensor, which the launch reads in place."""
+    ring = new_blocks.dim() == 2
+    dev = _need_gpu(tables, num_blocks, kv_lens, seq_lens, None if ring and not new_blocks.is_cuda
+                    else new_blocks, slot_mapping_out, attn_kv_lens_out, last_blocks_out)
     for t in (tables, num_blocks, kv_lens, seq_lens, new_blocks, attn_kv_lens_out):
         if t.dtype != torch.int32 or not t.is_contiguous():
             raise RuntimeError("table_state_advance: int32 contiguous tensors expected")
     if slot_mapping_out.dtype != torch.int64 or not slot_mapping_out.is_contiguous():
         raise RuntimeError("table_state_advance: slot_mapping_out must be contiguous int64")
     if tables.dim() != 2 or min(tables.shape[0], num_blocks.numel(), kv_lens.numel(), seq_lens.numel(),
-                                new_blocks.numel(), slot_mapping_out.numel(),
+                                new_blocks.shape[-1], slot_mapping_out.numel(),
                                 attn_kv_lens_out.numel()) < batch:
         raise RuntimeError("table_state_advance: state arrays shorter than the batch")
     lib = _lib.load()
+    if ring:
+        if not new_blocks.is_cuda and not new_blocks.is_pinned():
+            raise RuntimeError("table_state_advance: a host ring must be pinned memory")
+        if new_blocks.shape[0] < 2:
+            raise RuntimeError("table_state_advance: a ring has at least 2 rows")
+        _lib.check(lib.pe_table_state_advance_ring(
+            _p(tables), _p(num_blocks), _p(kv_lens), _p(seq_lens), _p(new_blocks), new_blocks.shape[0],
+            new_blocks.shape[1], batch, tables.shape[1], _p(slot_mapping_out), _p(attn_kv_lens_out),
+            _p(last_blocks_out), evict_rule, cache_budget, block_size, evict_freq, num_block_merge,
+            initial_blocks, _stream(dev)), "table_state_advance_ring")
+        return
     _lib.check(lib.pe_table_state_advance(
         _p(tables), _p(num_blocks), _p(kv_lens), _p(seq_lens), _p(new_blocks), batch, tables.shape[1],
         _p(slot_mapping_out), _p(attn_kv_lens_out), _p(last_blocks_out), evict_rule, cache_budget,
