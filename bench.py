@@ -364,6 +364,7 @@ class Workload:
         import numpy as np
         from vllm_paged_compression_amd import staging
         from vllm_paged_compression_amd.batch_scheduler import BatchEvictionScheduler
+        from vllm_paged_compression_amd.backend import percentage_decode_victims
         from vllm_paged_compression_amd.page_evict_kv_util import budget_decode_trigger
         a, bs = self.a, self.bs
         B, L0 = a.num_prompts, a.input_len
@@ -396,10 +397,11 @@ class Workload:
         es = 2
         use_graph = self.use_graph
         # an eviction step can be replayed too when its decision needs nothing from the host:
-        # budget type, victims chosen on the device (or fixed), one GPU (under tensor parallelism
-        # the scores take an all-reduce, left eager)
-        evict_graph = (use_graph and self.cfg is not None and not self.percentage and self.tp_group is None
-                       and self.cfg.evict_method in ("streamingLLM", "global", "local"))
+        # budget type with victims chosen on the device (or fixed), percentage type (the device
+        # derives each row's trigger from its resident counters); one GPU (under tensor
+        # parallelism the scores take an all-reduce, left eager)
+        evict_graph = (use_graph and self.cfg is not None and self.tp_group is None
+                       and (self.percentage or self.cfg.evict_method in ("streamingLLM", "global", "local")))
         warmed = "plain" in self._graphs
         warmed_ev = "evict" in self._graphs
         for it in range(a.output_len):
@@ -434,9 +436,14 @@ class Workload:
                 graph_ev.replay()
                 self.graph_replays += 1
                 self.graph_evict_replays += 1
-                # the victims feed the host's free list: one small read-back per eviction step
-                rmv = staging.AsyncReadback(rmv_dev[:B]).tolist()
-                sched.commit({i: (rids[i], r) for i, r in enumerate(rmv) if r >= 0})
+                if self.percentage:
+                    # nothing depends on the data: the host knows the freed columns
+                    sched.commit(percentage_decode_victims(self.cfg, batch.seq_lens, batch.table_lens,
+                                                           rids, bs))
+                else:
+                    # the victims feed the host's free list: one small read-back per eviction step
+                    rmv = staging.AsyncReadback(rmv_dev[:B]).tolist()
+                    sched.commit({i: (rids[i], r) for i, r in enumerate(rmv) if r >= 0})
             else:
                 if use_graph:
                     self._dev_state.launch_advance()

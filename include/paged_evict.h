@@ -513,7 +513,8 @@ int pe_evict_select_compact_inplace(int32_t* rmv_idx_out, int32_t* freed_blocks_
  * blocks from column initial_blocks into the first of them and drops the others.
  *
  * pe_merge_blocks_value_l2: for every listed row b (rows = device int32[n_rows] of batch
- *   indices) and every KV head, reads the num_block_merge blocks block_tables[b][first_block ..)
+ *   indices; a negative entry is skipped, so a list built on the device can switch rows off) and
+ *   every KV head, reads the num_block_merge blocks block_tables[b][first_block ..)
  *   of both caches, scores each of their tokens with ||V[token, head, :]||_2 (rounded to the
  *   storage type), keeps the block_size highest (equal scores: the lowest token goes first),
  *   and writes the kept K and V rows, in their original order, into block

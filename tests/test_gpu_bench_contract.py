@@ -92,14 +92,16 @@ def test_bench_presets_select_the_baseline_configs():
 
 
 @pytest.mark.parametrize("extra", [["--evict", "0"], [], ["--decode-evict-method", "streamingLLM"],
-                                   ["--cache-prune-type", "percentage", "--evict-freq", "2"]])
+                                   ["--cache-prune-type", "percentage", "--evict-freq", "2"],
+                                   ["--cache-prune-type", "percentage", "--evict-freq", "2",
+                                    "--decode-evict-method", "streamingLLM", "--num-block-merge", "3"]])
 def test_bench_graph_decode_leaves_the_same_kv_cache(extra):
     """--graph-decode replays the launches of the decode steps from HIP graphs - the steps that
-    evict nothing from one graph, the steps with an eviction decision of the budget prune type
-    from a second one whose victims are read back after the replay (the percentage type's
-    eviction steps stay eager); the KV caches of all layers must end bit-identical to the eager
-    run's, with the same blocks held.  Two generations: the second one replays graphs captured in
-    the first."""
+    evict nothing from one graph, the steps with an eviction decision from a second one (budget
+    type: the victims are read back after the replay; percentage type: block merges and table
+    compaction with every row's trigger derived on the device); the KV caches of all layers must
+    end bit-identical to the eager run's, with the same blocks held.  Two generations: the second
+    one replays graphs captured in the first."""
     env = dict(os.environ, PE_BENCH_KV_CHECKSUM="1")
     base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "0",
             "--num-prompts", "4", "--prefill-batch", "4", "--input-len", "200", "--output-len", "70",
@@ -112,8 +114,7 @@ def test_bench_graph_decode_leaves_the_same_kv_cache(extra):
         res.append(d["config"])
     assert res[0]["graph_decode"] is False and res[1]["graph_decode"] is True
     assert res[0]["graph_replays"] == 0 and res[1]["graph_replays"] > 100
-    budget_type = "--evict" not in extra and "--cache-prune-type" not in extra
-    assert (res[1]["graph_evict_replays"] > 0) == budget_type
+    assert (res[1]["graph_evict_replays"] > 0) == ("--evict" not in extra)
     assert res[0]["kv_checksum"] == res[1]["kv_checksum"] != 0
     assert res[0]["kv_gb_held_peak"] == res[1]["kv_gb_held_peak"]
 

@@ -1224,22 +1224,35 @@ class PagedEvictImpl(_ImplBase):
         trig_np = (L % (bs * cfg.evict_freq) == 0) & (table_lens > ib + nbm)
         dec: Dict[str, Any] = {"rmv": None, "tables": None, "zero_slots": None, "host_rmv": None,
                                "req_ids": None, "merge": None}
-        if not trig_np.any():
+        # under HIP-graph capture the launches must serve later steps too: the trigger of each row
+        # is then derived on the device from the resident counters (same arithmetic), and a step
+        # on which some row stands on a multiple of evict_freq blocks issues the launches whether
+        # or not that row holds enough blocks yet (the other steps launch nothing, captured or not:
+        # an engine keeps one graph for each of the two kinds of step)
+        capturing = st is not None and torch.cuda.is_current_stream_capturing() and \
+            bool((L % (bs * cfg.evict_freq) == 0).any())
+        if not trig_np.any() and not capturing:
             return dec
         dev = dm.block_tables.device
         value_l2 = cfg.decode_evict_method != "streamingLLM"     # a scored method: blocks are merged
         first_freed = ib + 1 if value_l2 else ib
         n_remove = nbm - 1
         M = dm.block_tables.shape[1]
-        start = staging.upload_i32(np.where(trig_np, first_freed, -1), dev)
-        dec["host_rmv"] = {int(i): (req_ids[i], first_freed) for i in np.nonzero(trig_np)[0]}
+        B = len(req_ids)
+        dec["host_rmv"] = percentage_decode_victims(cfg, L, table_lens, req_ids, bs)
+        if capturing:
+            trig_d = (st.seq_lens[:B] % (bs * cfg.evict_freq) == 0) & (st.num_blocks[:B] > ib + nbm)
+            start = torch.where(trig_d, first_freed, -1).to(torch.int32)
+            rows_d = torch.where(trig_d, torch.arange(B, device=dev), -1).to(torch.int32)
+        else:
+            start = staging.upload_i32(np.where(trig_np, first_freed, -1), dev)
+            rows_d = None
         if value_l2:
-            dec["merge"] = staging.upload_i32(np.nonzero(trig_np)[0], dev)
+            dec["merge"] = rows_d if capturing else staging.upload_i32(np.nonzero(trig_np)[0], dev)
             dec["merge_tables"] = dm.block_tables
         if st is not None:
             if self.compat.per_layer_decision:
                 raise NotImplementedError("device-resident block tables take one decision per step")
-            B = len(req_ids)
             if value_l2:
                 # the merged group's block ids, before their columns close
                 dec["merge_tables"] = st.tables[:B, :ib + nbm].clone()
@@ -1254,6 +1267,19 @@ class PagedEvictImpl(_ImplBase):
         width = min(max(int((table_lens - trig_np * n_remove).max()), 1), M)
         dec["tables"] = ops.block_table_remove_range(dm.block_tables, start, n_remove, width)
         return dec
+
+
+def percentage_decode_victims(cfg, logical_lens, table_lens, req_ids, block_size: int) -> Dict[int, Tuple[str, int]]:
+    """What ``get_rmv_block_idx()`` reports on a decode step of the percentage prune type
+    ({batch index: (request id, first freed column)}): host arithmetic on the step's logical
+    lengths and table lengths (trigger torch_cuda_sdpa.py:1310; columns
+    page_evict_kv_util_bak.py:66-106).  An engine that replays the step's launches from a HIP graph
+    calls it for the commit."""
+    ib, nbm = cfg.initial_blocks, cfg.num_block_merge
+    L = np.asarray(logical_lens)
+    trig = (L % (block_size * cfg.evict_freq) == 0) & (np.asarray(table_lens) > ib + nbm)
+    first_freed = ib + 1 if cfg.decode_evict_method != "streamingLLM" else ib
+    return {int(i): (req_ids[i], first_freed) for i in np.nonzero(trig)[0]}
 
 
 def _layer_index(prefix: str) -> int:

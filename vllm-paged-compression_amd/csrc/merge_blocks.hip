@@ -33,6 +33,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_blocks_kernel(
   float* score = reinterpret_cast<float*>(v_s + (size_t)num_merge * slab);  // [n_tok]
   int* dest = reinterpret_cast<int*>(score + num_merge * block_size);       // [n_tok]
   const int b = rows[blockIdx.x];
+  if (b < 0) return;  // an entry switched off by the caller (the whole workgroup leaves)
   const int h = blockIdx.y;
   const int tid = threadIdx.x;
   const int n_tok = num_merge * block_size;
