@@ -82,7 +82,7 @@ def main():
     print("B Hq Hkv D kv | " + " ".join(f"{w}w/{s}s".rjust(7) for w, s in COMBOS))
     for shp in SHAPES:
         r = time_shape(*shp)
-        best = min(range(1, len(COMBOS)), key=lambda i: r[i] if r[i] == r[i] else 1e9)
+        best = min(range(min(1, len(COMBOS) - 1), len(COMBOS)), key=lambda i: r[i] if r[i] == r[i] else 1e9)
         print(" ".join(str(x) for x in shp) + " | " + " ".join(f"{t:7.2f}" for t in r)
               + f"   best {COMBOS[best][0]}w/{COMBOS[best][1]}s", flush=True)
 

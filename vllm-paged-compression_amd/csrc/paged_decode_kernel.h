@@ -31,6 +31,13 @@ constexpr float NEG_BIG = -1.0e30f;
 // it (a caller bug the launch itself survives); read back through pe_device_diagnostics.
 static __device__ unsigned int decode_diag_word;
 
+// A K/V fragment load with or without the non-temporal hint
+template <bool NT, typename V>
+__device__ __forceinline__ V ldg(const V* p) {
+  if constexpr (NT) return __builtin_nontemporal_load(p);
+  else return *p;
+}
+
 template <typename T, int HEAD_SIZE>
 struct DecTile {
   typename Traits<T>::vec8 k[2][(HEAD_SIZE + 31) / 32];
@@ -93,6 +100,11 @@ void paged_decode_mfma_kernel(
   constexpr bool RAGGED_K = HEAD_SIZE % 32 != 0;
   constexpr bool RAGGED_V = HEAD_SIZE % 16 != 0;
   constexpr int BS = 16;              // tokens per tile half
+  // K/V loads of the throughput shape carry the non-temporal hint: a launch that streams more
+  // than the caches hold keeps nothing worth keeping (measured: 35.4 against 39.7 us at 200 MB
+  // per launch).  The latency shapes serve launches of a few megabytes, which run faster with
+  // plain loads (one sequence of kv 776: 7.7 against 8.3 us).
+  constexpr bool STREAM = WAVES < 8;
   static_assert(BLK == 8 || BLK == 16 || BLK == 32, "block size");
   static_assert(HEAD_SIZE % 8 == 0 && (BLK == 16 || HEAD_SIZE % 32 == 0), "head size");
 
@@ -267,13 +279,13 @@ void paged_decode_mfma_kernel(
       const T* vp = value_cache + pa * kv_block_stride + head_off + hc * BLK + 4 * g;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        t.k[0][ks] = __builtin_bit_cast(vec8, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kp + ks * (4 * BLK * 8))));
-        t.k[1][ks] = __builtin_bit_cast(vec8, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kp + ks * (4 * BLK * 8) + BS * 8)));
+        t.k[0][ks] = __builtin_bit_cast(vec8, ldg<STREAM>(reinterpret_cast<const u32x4*>(kp + ks * (4 * BLK * 8))));
+        t.k[1][ks] = __builtin_bit_cast(vec8, ldg<STREAM>(reinterpret_cast<const u32x4*>(kp + ks * (4 * BLK * 8) + BS * 8)));
       }
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
-        t.v[0][dt] = __builtin_bit_cast(vec4, __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(vp + dt * 16 * BLK)));
-        t.v[1][dt] = __builtin_bit_cast(vec4, __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(vp + dt * 16 * BLK + BS)));
+        t.v[0][dt] = __builtin_bit_cast(vec4, ldg<STREAM>(reinterpret_cast<const u32x2*>(vp + dt * 16 * BLK)));
+        t.v[1][dt] = __builtin_bit_cast(vec4, ldg<STREAM>(reinterpret_cast<const u32x2*>(vp + dt * 16 * BLK + BS)));
       }
       return;
     }
@@ -294,13 +306,13 @@ void paged_decode_mfma_kernel(
       const T* vb = value_cache + (g < 2 ? p2 : p3) * kv_block_stride + head_off + voff;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        t.k[0][ks] = __builtin_bit_cast(vec8, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ka + ks * (4 * BLK * 8))));
-        t.k[1][ks] = __builtin_bit_cast(vec8, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kb + ks * (4 * BLK * 8))));
+        t.k[0][ks] = __builtin_bit_cast(vec8, ldg<STREAM>(reinterpret_cast<const u32x4*>(ka + ks * (4 * BLK * 8))));
+        t.k[1][ks] = __builtin_bit_cast(vec8, ldg<STREAM>(reinterpret_cast<const u32x4*>(kb + ks * (4 * BLK * 8))));
       }
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
-        t.v[0][dt] = __builtin_bit_cast(vec4, __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(va + dt * 16 * BLK)));
-        t.v[1][dt] = __builtin_bit_cast(vec4, __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(vb + dt * 16 * BLK)));
+        t.v[0][dt] = __builtin_bit_cast(vec4, ldg<STREAM>(reinterpret_cast<const u32x2*>(va + dt * 16 * BLK)));
+        t.v[1][dt] = __builtin_bit_cast(vec4, ldg<STREAM>(reinterpret_cast<const u32x2*>(vb + dt * 16 * BLK)));
       }
       return;
     }
@@ -318,8 +330,8 @@ void paged_decode_mfma_kernel(
         t.k[0][ks] = t.k[1][ks] = __builtin_bit_cast(vec8, u32x4{0u, 0u, 0u, 0u});
         continue;
       }
-      t.k[0][ks] = __builtin_bit_cast(vec8, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(ka + ks * 512)));
-      t.k[1][ks] = __builtin_bit_cast(vec8, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kb + ks * 512)));
+      t.k[0][ks] = __builtin_bit_cast(vec8, ldg<STREAM>(reinterpret_cast<const u32x4*>(ka + ks * 512)));
+      t.k[1][ks] = __builtin_bit_cast(vec8, ldg<STREAM>(reinterpret_cast<const u32x4*>(kb + ks * 512)));
     }
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
@@ -327,8 +339,8 @@ void paged_decode_mfma_kernel(
         t.v[0][dt] = t.v[1][dt] = __builtin_bit_cast(vec4, u32x2{0u, 0u});
         continue;
       }
-      t.v[0][dt] = __builtin_bit_cast(vec4, __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(va + dt * 16 * BS)));
-      t.v[1][dt] = __builtin_bit_cast(vec4, __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(vb + dt * 16 * BS)));
+      t.v[0][dt] = __builtin_bit_cast(vec4, ldg<STREAM>(reinterpret_cast<const u32x2*>(va + dt * 16 * BS)));
+      t.v[1][dt] = __builtin_bit_cast(vec4, ldg<STREAM>(reinterpret_cast<const u32x2*>(vb + dt * 16 * BS)));
     }
   };
 
