@@ -263,3 +263,32 @@ def test_oracle_readme_prune_and_merge_golden(oracle):
         for h in range(H):
             mask[keep[h], h] = True
         assert torch.equal(k[mask].view(-1, H, D), from_bits(z[f"d{c}_pk"], 0)), (c, OLD_METHODS[mi])
+
+
+def test_percentage_decode_victims_follow_the_trigger_and_the_reference_columns(oracle):
+    """backend.percentage_decode_victims (what a graph-replaying engine commits without a
+    read-back): a row is listed exactly when page_evict_kv_util.percentage_decode_trigger fires
+    for it, with the first freed column of the reference's get_blocks_to_prune
+    (page_evict_kv_util_bak.py:66-106; fixtures in percentage_tables.json via the oracle)."""
+    import numpy as np
+    from vllm_paged_compression_amd.backend import percentage_decode_victims
+    from vllm_paged_compression_amd.config import PagedEvictConfig
+    from vllm_paged_compression_amd.page_evict_kv_util import percentage_decode_trigger
+    BS = 16
+    rng = np.random.default_rng(3)
+    for method, freq, nbm in (("streamingLLM", 2, 2), ("value_l2", 2, 2), ("value_l2", 4, 3), ("cosine", 3, 2)):
+        cfg = PagedEvictConfig(True, "percentage", "streamingLLM", 0, 1, evict_freq=freq, num_block_merge=nbm,
+                               prompt_evict_method="streamingLLM", decode_evict_method=method)
+        n_tab = rng.integers(1, 12, 40)
+        L = n_tab * BS + rng.integers(0, 5, 40) * BS * freq      # many rows on a multiple of freq blocks
+        L[::3] += 5
+        ids = [f"r{i}" for i in range(40)]
+        got = percentage_decode_victims(cfg, L, n_tab, ids, BS)
+        for i in range(40):
+            first, n, _ = oracle.percentage_decode_blocks(int(L[i]), int(n_tab[i]), BS, freq, method,
+                                                          cfg.initial_blocks, nbm)
+            fires = percentage_decode_trigger(cfg, int(L[i]), int(n_tab[i]) * BS, BS)
+            assert (i in got) == fires == (first >= 0)
+            if fires:
+                assert got[i] == (ids[i], first) and n == nbm - 1
+        assert got
