@@ -10,7 +10,7 @@ import test_gpu_fuzz as F
 fn = F.test_continuous_batching_fuzz
 cases = [("streamingLLM", False), ("streamingLLM-1", False), ("global", False), ("local", False),
          ("streamingLLM", True), ("global", True), ("local", True), ("pct:streamingLLM", False), ("pct:value_l2", False), ("pct:value_l2", True),
-         ("pct3:value_l2", False), ("pct3:streamingLLM", True),
+         ("pct3:value_l2", False), ("pct3:streamingLLM", True), ("pct:cosine", False), ("pct3:value_l1_div_key_l2", True),
          ("bs8:global", False), ("bs32:streamingLLM-1", False), ("bs32:local", True), ("bs8:streamingLLM", True)]
 t0 = time.time(); n = fails = 0
 lo, hi = int(sys.argv[1]), int(sys.argv[2])

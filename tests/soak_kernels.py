@@ -4,7 +4,8 @@ Per seed: one decode-attention case (random head geometry, dtype, sequence lengt
 block / tile boundaries over-represented, random block tables, optionally ALiBi, a random forced
 split count), the same case through the fused decode step (KV write inside the launch; cache
 bytes must equal the separate write), and one prefill case (random ragged prompts, kv lengths
-shorter than the prompts for some requests, every tile shape the launcher can pick).  Tolerances
+shorter than the prompts for some requests, every tile shape the launcher can pick), and one
+rotating decode step (rotation inside the launch against rotation in front of it).  Tolerances
 are the ones of tests/test_gpu_kernels.py.  Not collected by pytest (long-running driver)."""
 import os
 import random
@@ -124,12 +125,81 @@ def prefill_case(seed):
     return f"prefill Hq{Hq} Hkv{Hkv} D{D} {str(dtype)[6:]} q{q_lens} kv{kv_lens}"
 
 
+def rope_case(seed):
+    """The rotating decode step (rotation + KV write + attention in one launch) against rotation in
+    its own launch followed by the plain step (bit for bit), and the cache bytes against the
+    oracle's rotation + write."""
+    from test_oracle_golden import rope_cache
+    rng = random.Random(seed * 13 + 5)
+    g = torch.Generator().manual_seed(seed * 13 + 5)
+    D = rng.choice([64, 128])
+    Hkv = rng.choice([1, 2, 8])
+    Hq = Hkv * rng.choice([1, 2, 4, 8])
+    dtype = rng.choice([torch.bfloat16, torch.float16])
+    bs = rng.choice([16, 8, 32])
+    is_neox = rng.random() < 0.6
+    rot = rng.choice([D, 64]) if is_neox else rng.choice([D, D // 2, 16, 48 if D == 64 else 80])
+    S = rng.randint(1, 9)
+    hi = rng.choice([80, 600, 1500])
+    lens = [pick_len(rng, hi) for _ in range(S)]
+    nb = sum((n + bs - 1) // bs for n in lens) + 4
+    sc = D ** -0.5
+    max_pos = 2048
+    cs = rope_cache(max_pos, rot, dtype)
+    pos = torch.randint(0, max_pos, (S,), generator=g)
+    kc = ((torch.rand(nb, Hkv, D // 8, bs, 8, generator=g) * 2 - 1) * sc).to(dtype)
+    vc = ((torch.rand(nb, Hkv, D, bs, generator=g) * 2 - 1) * sc).to(dtype)
+    qkv = ((torch.rand(S, (Hq + 2 * Hkv) * D, generator=g) * 2 - 1) * 4 * sc).to(dtype)
+    perm = torch.randperm(nb, generator=g).tolist()
+    M = max((n + bs - 1) // bs for n in lens) + rng.randint(0, 2)
+    bt = torch.zeros(S, M, dtype=torch.int32)
+    for i, n in enumerate(lens):
+        for j in range((n + bs - 1) // bs):
+            bt[i, j] = perm.pop()
+    slots = torch.tensor([int(bt[i, (n - 1) // bs]) * bs + (n - 1) % bs for i, n in enumerate(lens)],
+                         dtype=torch.int64)
+    lens_t = torch.tensor(lens, dtype=torch.int32)
+    splits = rng.choice([0, 0, 2, 3])
+    if splits:
+        os.environ["PE_DECODE_SPLITS"] = str(splits)
+    else:
+        os.environ.pop("PE_DECODE_SPLITS", None)
+    ops.reload_env()
+    assert ops.decode_step_rope_supported(Hq, Hkv, D, bs, dtype, rot, is_neox)
+
+    def views(t):
+        return (x.reshape(S, -1, D) for x in t.split([Hq * D, Hkv * D, Hkv * D], dim=-1))
+    qkv1 = qkv.cuda()
+    q1, k1, v1 = views(qkv1)
+    kc1, vc1 = kc.cuda(), vc.cuda()
+    o1 = torch.empty(S, Hq, D, dtype=dtype, device="cuda")
+    ops.decode_step_rope(o1, pos.cuda(), q1, k1, v1, kc1, vc1, slots.cuda(), Hkv, sc, bt.cuda(), lens_t.cuda(),
+                         bs, max(lens), cs.cuda(), is_neox)
+    assert torch.equal(qkv1.cpu(), qkv), "inputs were rotated in place"
+    qkv2 = qkv.cuda()
+    q2, k2, v2 = views(qkv2)
+    kc2, vc2 = kc.cuda(), vc.cuda()
+    ops.rotary_embedding(pos.cuda(), q2, k2, D, cs.cuda(), is_neox)
+    o2 = torch.empty_like(o1)
+    ops.decode_step(o2, q2, k2, v2, kc2, vc2, slots.cuda(), Hkv, sc, bt.cuda(), lens_t.cuda(), bs, max(lens))
+    assert torch.equal(kc1, kc2) and torch.equal(vc1, vc2), "cache bytes differ from the two-launch form"
+    assert torch.equal(o1, o2), "output differs from the two-launch form"
+    q, k, v = views(qkv)
+    k_ref = oracle.rotary_embedding(pos, k.reshape(S, -1), D, cs, is_neox).reshape(S, Hkv, D)
+    kc_ref, vc_ref = kc.clone(), vc.clone()
+    oracle.reshape_and_cache(k_ref, v.contiguous(), kc_ref, vc_ref, slots)
+    assert torch.equal(kc1.cpu(), kc_ref) and torch.equal(vc1.cpu(), vc_ref), "cache bytes differ from the oracle"
+    os.environ.pop("PE_DECODE_SPLITS", None)
+    ops.reload_env()
+    return f"rope Hq{Hq} Hkv{Hkv} D{D} bs{bs} rot{rot} neox{is_neox} {str(dtype)[6:]} S{S} max{max(lens)} splits{splits}"
+
+
 def main():
     lo, hi = int(sys.argv[1]), int(sys.argv[2])
     t0 = time.time()
     fails = 0
     for seed in range(lo, hi):
-        for fn in (decode_case, prefill_case):
+        for fn in (decode_case, prefill_case, rope_case):
             try:
                 desc = fn(seed)
             except Exception as e:     # noqa: BLE001

@@ -246,3 +246,32 @@ def test_compaction_and_streaming_index_full_size(ops, oracle):
     assert (rel == rel[0]).all()
     assert torch.equal(rel[0, :BS], torch.arange(BS, device="cuda"))
     assert torch.equal(rel[0, -BS:], torch.arange(L - BS, L, device="cuda"))
+
+
+@pytest.mark.parametrize("method", ["cosine", "key_l2_div_value_l1"])
+def test_readme_score_prune_full_size(ops, oracle, method):
+    """The percentage type's prompt prune under a README-era token score at the headline's prefill
+    size (8 prompts of 1024 tokens, 8 KV heads x 128): the kept rows of every prompt against the
+    oracle's prune of that prompt (bit-exact: same scores, same order), and size-independent
+    properties over the whole batch - every prompt keeps the same number of rows, its first block
+    and its tail untouched."""
+    from vllm_paged_compression_amd.pruner import KVCachePruner
+    g = torch.Generator().manual_seed(31)
+    n, L, H, D = 8, 1024, 8, 128
+    k = (torch.rand(n * L, H, D, generator=g) * 2 - 1).to(torch.bfloat16)
+    v = (torch.rand(n * L, H, D, generator=g) * 2 - 1).to(torch.bfloat16)
+    p = KVCachePruner("percentage", method, BS, 0, 1, evict_freq=2, decode_evict_method="streamingLLM")
+    pk, pv, kept = p.prune_prompts_batch(k.cuda(), v.cuda(), [L] * n)
+    assert len(set(kept)) == 1 and sum(kept) == pk.shape[0] == pv.shape[0]
+    K = kept[0]
+    for i in (0, 3, 7):
+        ek, ev = oracle.percentage_prompt_prune(k[i * L:(i + 1) * L], v[i * L:(i + 1) * L], method, BS, 2)
+        assert ek.shape[0] == K
+        assert torch.equal(pk[i * K:(i + 1) * K].cpu(), ek) and torch.equal(pv[i * K:(i + 1) * K].cpu(), ev)
+    pk3, k3 = pk.view(n, K, H, D).cpu(), k.view(n, L, H, D)
+    assert torch.equal(pk3[:, :BS], k3[:, :BS])                     # the first block stays
+    end_first, end_mid, n_prune = oracle.percentage_prompt_slices(L, BS, 2, 1, 2)
+    tail = L - end_mid
+    if tail:
+        assert torch.equal(pk3[:, K - tail:], k3[:, end_mid:])      # and so does the tail
+    assert K == L - n_prune

@@ -28,6 +28,8 @@ def _rand(T, H, g, scale):
     ("local", 4, False), ("streamingLLM", 5, True), ("global", 6, True),
     ("pct:streamingLLM", 7, False), ("pct:value_l2", 8, False), ("pct:value_l2", 9, True),
     ("pct3:value_l2", 10, False), ("pct3:streamingLLM", 11, False),
+    # merges ranked by other token scores of the README era (kvcache_prunner_old.py:77-134)
+    ("pct:cosine", 17, False), ("pct3:key_l1_div_value_l2", 18, False),
     # the other two page sizes of the reference's scripts/diff_page_sizes.sh
     ("bs8:global", 12, False), ("bs32:global", 13, False), ("bs8:streamingLLM-1", 14, False),
     ("bs32:streamingLLM", 15, True), ("bs32:local", 16, False)])
@@ -215,7 +217,7 @@ def test_continuous_batching_fuzz(oracle, method, seed, evict_before_prefill, ve
                     oracle.reshape_and_cache(z, z, kc_cpu[li], vc_cpu[li], torch.tensor(zero_slots))
                 for i, mg in enumerate(merged):
                     if mg is not None:
-                        oracle.merge_blocks_in_cache(kc_cpu[li], vc_cpu[li], tbls[i][mg[0]:mg[1]])
+                        oracle.merge_blocks_in_cache(kc_cpu[li], vc_cpu[li], tbls[i][mg[0]:mg[1]], method)
                 assert torch.equal(kv_gpu[li][0].view_as(kc_cpu[li]).cpu(), kc_cpu[li]), (step, li)
                 assert torch.equal(kv_gpu[li][1].view_as(vc_cpu[li]).cpu(), vc_cpu[li]), (step, li)
                 ref = oracle.paged_attention(q.view(B, HQ, D), kc_cpu[li], vc_cpu[li], use_tables,
