@@ -186,18 +186,30 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void prefill_mfma_kernel(
   const uint32_t v_lane_off = (uint32_t)lrow * v_row_bytes + v_chunk16;
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem +
                         (uint32_t)wave * 1024u;
-  auto glds16 = [](const char* base, uint32_t lane_off, uint32_t lds_dst) {
-    unsigned keep;
-    asm volatile(
-        "s_nop 4\n\t"
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %3\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %2\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(lane_off), "s"(base), "s"(lds_dst)
-        : "memory");
+  // M0 carries the LDS destination of an LDS-DMA load and nothing else in this kernel (the
+  // compiler keeps no value in it: every access to M0 in the generated code is one of the moves
+  // below).  A load may not read an SGPR that a vector
+  // instruction wrote fewer than 5 issue slots earlier: the first load of a tile waits that out;
+  // the operands of the following ones are scalar sums of values that existed before it.
+  auto glds16 = [](const char* base, uint32_t lane_off, uint32_t lds_dst, auto first_tag) {
+    if constexpr (decltype(first_tag)::value) {
+      asm volatile(
+          "s_nop 4\n\t"
+          "s_mov_b32 m0, %2\n\t"
+          "s_nop 0\n\t"
+          "global_load_lds_dwordx4 %0, %1"
+          :
+          : "v"(lane_off), "s"(base), "s"(lds_dst)
+          : "memory");
+    } else {
+      asm volatile(
+          "s_mov_b32 m0, %2\n\t"
+          "s_nop 0\n\t"
+          "global_load_lds_dwordx4 %0, %1"
+          :
+          : "v"(lane_off), "s"(base), "s"(lds_dst)
+          : "memory");
+    }
   };
   auto stage = [&](int tile, int buf) {
     const int t0 = tile * PF_BN;
@@ -206,18 +218,25 @@ __global__ __launch_bounds__(WAVES * 64, WPE) void prefill_mfma_kernel(
     const uint32_t kd = lds0 + (uint32_t)buf * (2u * TILE_BYTES);
     const uint32_t vd = kd + TILE_BYTES;
     if (t0 + PF_BN <= lkv) {
+      glds16(kb, k_lane_off, kd, std::true_type{});
+      glds16(vb, v_lane_off, vd, std::false_type{});
 #pragma unroll
-      for (int i = 0; i < NINST; ++i) {
-        glds16(kb + (int64_t)(i * RSTEP) * k_row_bytes, k_lane_off, kd + i * RSTEP * D * 2);
-        glds16(vb + (int64_t)(i * RSTEP) * v_row_bytes, v_lane_off, vd + i * RSTEP * D * 2);
+      for (int i = 1; i < NINST; ++i) {
+        glds16(kb + (int64_t)(i * RSTEP) * k_row_bytes, k_lane_off, kd + i * RSTEP * D * 2, std::false_type{});
+        glds16(vb + (int64_t)(i * RSTEP) * v_row_bytes, v_lane_off, vd + i * RSTEP * D * 2, std::false_type{});
       }
     } else {
       const int last = lkv - 1 - t0;  // >= 0: a staged tile starts inside the request
 #pragma unroll
       for (int i = 0; i < NINST; ++i) {
         const uint32_t row = (uint32_t)min(lrow + i * RSTEP, last);
-        glds16(kb, row * k_row_bytes + k_chunk16, kd + i * RSTEP * D * 2);
-        glds16(vb, row * v_row_bytes + v_chunk16, vd + i * RSTEP * D * 2);
+        // (the row offsets are per-lane values, the scalar operands are the first load's)
+        if (i == 0) {
+          glds16(kb, row * k_row_bytes + k_chunk16, kd, std::true_type{});
+        } else {
+          glds16(kb, row * k_row_bytes + k_chunk16, kd + i * RSTEP * D * 2, std::false_type{});
+        }
+        glds16(vb, row * v_row_bytes + v_chunk16, vd + i * RSTEP * D * 2, std::false_type{});
       }
     }
   };
