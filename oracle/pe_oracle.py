@@ -24,7 +24,7 @@ import ctypes
 import os
 import random
 import subprocess
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 

@@ -18,7 +18,6 @@ def main():
     wl = bench.Workload(a, dev, 1, 0, None)
     wl.generate()
     torch.cuda.synchronize()
-    from vllm_paged_compression_amd.batch_scheduler import BatchEvictionScheduler
     marks = []
     orig_layers = wl._layers
 

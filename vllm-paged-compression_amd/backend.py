@@ -20,7 +20,7 @@ What differs from the reference by design:
 from __future__ import annotations
 
 import random
-from dataclasses import dataclass, field, fields
+from dataclasses import dataclass, fields
 from itertools import accumulate
 from typing import Any, Dict, List, Optional, Tuple, Type
 

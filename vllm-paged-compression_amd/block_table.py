@@ -19,7 +19,7 @@ Method names keep the reference's spelling (``free_prunned_blocks``).
 from __future__ import annotations
 
 from collections import deque
-from typing import Deque, Dict, List, Optional, Tuple
+from typing import Deque, Dict, List, Tuple
 
 from .page_evict_kv_util import cdiv, get_num_required_blocks_after_prune_promt
 

@@ -10,7 +10,7 @@ the host waits for that copy only and not for everything queued after it.
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 import torch
