@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs on the GPU box (through gpurun): for the BASELINE configurations the bench line, the
-# rocprofv3 kernel statistics of the same command and (c2, c3) the two HBM-traffic counter passes
+# rocprofv3 kernel statistics of the same command and (c2 to c5) the two HBM-traffic counter passes
 # of the decode kernel inside the bench; for the prefill kernel the SQ counter passes on the two
 # shapes it is tracked on.  Output goes to gpurun_out/prof/; tools/summarize_profiles.py turns
 # it into profiles/.   CONFIGS="c2 c3" selects configurations, PREFILL=0 skips the prefill passes.
@@ -24,7 +24,7 @@ for c in ${CONFIGS:-c2 c1 c3 c4 c5}; do
         python3 "$R/bench.py" $rshort > "$O/bench_under_rocprof_$c.json" 2> "$O/stats_$c.err"
     rm -f "$O/stats_$c/bench_kernel_trace.csv"
   fi
-  if [ "$c" = c2 ] || [ "$c" = c3 ] || [ "$c" = c4 ]; then
+  if [ "$c" = c2 ] || [ "$c" = c3 ] || [ "$c" = c4 ] || [ "$c" = c5 ]; then
     echo "== $c FETCH_SIZE $(date +%T)"
     timeout -s KILL 500 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fetch_$c" -o fetch -- \
         python3 "$R/bench.py" $short --steps 1 --warmup 0 > /dev/null 2> "$O/pmc_fetch_$c.err"
