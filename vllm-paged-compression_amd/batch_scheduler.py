@@ -59,7 +59,8 @@ class DeviceTableState:
     arguments at every step): no copy is queued, and the launch can be a node of a replayed HIP
     graph.  With ``defer_advance`` set, ``advance`` only stores the step's entries and the engine
     issues the launch itself - ``launch_advance()``, eagerly or captured at the head of the
-    step's graph."""
+    step's graph.  A graph that captured the launch reads this object's buffers at every replay:
+    the state must outlive the graph (a new scheduler adopts it through ``device_state=``)."""
 
     RING = 64      # steps the host may run ahead of the device, kept below this by events
     _GUARD = 16    # an event every so many steps
