@@ -166,7 +166,7 @@ int pe_reshape_and_cache(const void* key, const void* value, void* key_cache,
  * softmax follows the CUDA kernel: p = exp(l - max) / (sum + 1e-6) (:342).
  * Kernel choice: 16-bit dtypes with block_size 16 (every head size of the reference's op,
  * vllm/attention/ops/paged_attn.py:37: 32, 64, 80, 96, 112, 120, 128, 192, 256) or block_size
- * 8/32 (head_size 64/128), up to 16 query heads per KV head and strides that are multiples of 8
+ * 8/32 (head sizes that are multiples of 32), up to 16 query heads per KV head and strides that are multiples of 8
  * elements run the matrix-core kernel, which reads K/V once per KV head; everything else (f32,
  * other block sizes, more query heads per KV head) runs a general kernel with the same results
  * and no tuning.

@@ -62,12 +62,15 @@ def test_argument_checks_without_gpu():
     p = 1 << 20
     assert lib.pe_paged_decode_supports_fused_write(32, 8, 128, 4, 2) == 0
     assert [lib.pe_paged_decode_supports_fused_write(32, 8, 128, b, 2) for b in (8, 16, 32)] == [1, 1, 1]
-    assert lib.pe_paged_decode_supports_fused_write(32, 8, 256, 32, 2) == 0
+    # 8- and 32-token blocks: the head sizes whose rows are whole 32-element k-steps
+    assert [lib.pe_paged_decode_supports_fused_write(32, 8, d, b, 2) for d in (32, 96, 192, 256)
+            for b in (8, 32)] == [1] * 8
+    assert [lib.pe_paged_decode_supports_fused_write(32, 8, d, b, 2) for d in (80, 112, 120)
+            for b in (8, 32)] == [0] * 6
     # every head size of the reference's op (paged_attn.py:37) with 16-token blocks; nothing else
     assert [lib.pe_paged_decode_supports_fused_write(32, 8, d, 16, 2)
             for d in (32, 64, 80, 96, 112, 120, 128, 192, 256)] == [1] * 9
     assert [lib.pe_paged_decode_supports_fused_write(32, 8, d, 16, 2) for d in (16, 48, 72, 160, 512)] == [0] * 5
-    assert lib.pe_paged_decode_supports_fused_write(32, 8, 96, 32, 2) == 0
     rc = lib.pe_decode_step(p, p, p, p, p, p, p, p, p, None, 1, 32, 8, 128, 4, 4, 4, 4096, 1024, 1024,
                             8192, 1024, 0.1, 32, 2, None, 0, None)
     assert rc == 2 and b"fused KV write" in lib.pe_last_error()

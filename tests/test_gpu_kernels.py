@@ -171,7 +171,8 @@ DECODE_CASES = [
     (24, 8, 128, 16, torch.bfloat16, [777, 784, 15]), (24, 8, 128, 8, torch.bfloat16, [777, 9]),
     (24, 8, 128, 32, torch.bfloat16, [777, 33]), (32, 8, 64, 16, torch.bfloat16, [1040, 17]),
     (32, 8, 64, 8, torch.bfloat16, [1040, 17]),
-    (16, 1, 256, 32, torch.bfloat16, [130, 33]),      # generic path (head size 256 with 32-token blocks)
+    (16, 1, 256, 32, torch.bfloat16, [130, 33]),      # head size 256 with 32-token blocks
+    (16, 2, 80, 32, torch.bfloat16, [130, 33]),       # generic path (head size 80 with 32-token blocks)
     (8, 2, 128, 16, torch.float32, [50, 333]),        # generic path (f32)
     (34, 2, 128, 16, torch.bfloat16, [70, 200]),      # 17 query heads per KV head -> generic
     # the remaining head sizes of the reference's sweep (tests/kernels/test_attention.py:30)
@@ -179,7 +180,12 @@ DECODE_CASES = [
     (8, 8, 112, 16, torch.float16, [129, 16]),
     (6, 2, 120, 16, torch.bfloat16, [200, 31]),
     (8, 2, 192, 16, torch.bfloat16, [90, 513]),
-    (8, 2, 192, 32, torch.float16, [65, 300]),        # generic path (head size 192 with 32-token blocks)
+    (8, 2, 192, 32, torch.float16, [65, 300]),        # head size 192 with 32-token blocks
+    # 8- and 32-token blocks at the other head sizes made of whole k-steps
+    (8, 8, 32, 8, torch.bfloat16, [1, 7, 8, 9, 33, 1500]), (8, 2, 32, 32, torch.float16, [31, 32, 33, 700]),
+    (16, 2, 96, 8, torch.bfloat16, [1, 15, 16, 17, 2049]), (12, 4, 96, 32, torch.float16, [64, 65, 900]),
+    (32, 8, 192, 8, torch.bfloat16, [9, 777, 2500]), (16, 2, 256, 8, torch.float16, [8, 9, 130, 1100]),
+    (16, 2, 256, 32, torch.bfloat16, [1, 33, 2000]),
     # every head size of the reference's op (vllm/attention/ops/paged_attn.py:37) on the matrix-core
     # kernel, lengths on and around the 32-token tile and long enough for several KV splits
     (8, 8, 32, 16, torch.bfloat16, [1, 31, 32, 33, 1500]),
@@ -779,12 +785,12 @@ def disjoint_tables(lens, bs, nb, g):
 def test_decode_step_fused_write(ops, oracle, Hq, Hkv, D, dtype, splits, bs, monkeypatch):
     """One launch (KV write + attention) == reshape_and_cache followed by paged attention:
     cache bytes identical, outputs within the kernel tolerance.  Block sizes 8, 16 and 32 (the
-    page sizes of the reference's scripts/diff_page_sizes.sh) all run the MFMA kernel for head
-    sizes 64 and 128; every other head size of the reference's op (paged_attn.py:37) runs it with
-    16-token blocks."""
-    if bs != 16 and D not in (64, 128):
+    page sizes of the reference's scripts/diff_page_sizes.sh) all run the MFMA kernel for the head
+    sizes made of whole 32-element k-steps (32, 64, 96, 128, 192, 256); 80, 112 and 120
+    (paged_attn.py:37) run it with 16-token blocks."""
+    if bs != 16 and D % 32:
         assert not ops._lib.load().pe_paged_decode_supports_fused_write(Hq, Hkv, D, bs, 2)
-        pytest.skip("8- and 32-token blocks are built for head sizes 64 and 128")
+        pytest.skip("8- and 32-token blocks are built for head sizes made of whole 32-element k-steps")
     if splits:
         monkeypatch.setenv("PE_DECODE_SPLITS", str(splits))
     g = torch.Generator().manual_seed(Hq + D)

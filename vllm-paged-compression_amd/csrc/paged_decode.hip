@@ -255,8 +255,8 @@ static bool mfma_path_ok(int num_heads, int num_kv_heads, int head_size, int blo
       head_size != 120 && head_size != 128 && head_size != 192 && head_size != 256)
     return false;
   // 8- and 32-token blocks (the page sizes of scripts/diff_page_sizes.sh:16) are built for the
-  // head sizes of the models that study runs (64, 128)
-  if (block_size != 16 && head_size != 64 && head_size != 128) return false;
+  // head sizes whose rows are whole 32-element k-steps (32, 64, 96, 128, 192, 256)
+  if (block_size != 16 && head_size % 32 != 0) return false;
   if (num_heads / num_kv_heads > 16) return false;
   if (q_stride % 8 || kv_block_stride % 8 || kv_head_stride % 8) return false;
   return true;
@@ -296,6 +296,9 @@ int decode_diag_fetch(unsigned int* out, int reset) {
   unsigned int a = 0, b = 0;
   if (int rc = decode_diag_fetch_tu(&a, reset)) return rc;
   if (int rc = decode_hs_diag_fetch(&b, reset)) return rc;
+  unsigned int c = 0;
+  if (int rc = decode_blk_diag_fetch(&c, reset)) return rc;
+  b |= c;
   *out = a | b;
   return PE_OK;
 }
@@ -361,7 +364,11 @@ static int decode_impl(void* out, const void* query, const void* key_cache, cons
                  num_heads, num_kv_heads, max_num_blocks_per_seq, q_stride, kv_block_stride,
                  kv_head_stride, scale, splits, new_key, new_value, new_slots, new_k_stride,
                  new_v_stride, num_slots, rope, grid, lds, st};
-    if (head_size != 64 && head_size != 128 && head_size != 256) {
+    if (block_size != 16 && head_size != 64 && head_size != 128) {
+      // 8- / 32-token blocks of the other head sizes: no rotating form, 4- or 8-wave workgroups
+      if (int rc = launch_decode_other_blocks(la, head_size, block_size, waves >= 8 ? 8 : DEC_WAVES, dtype))
+        return rc;
+    } else if (head_size != 64 && head_size != 128 && head_size != 256) {
       // the other head sizes: 16-token blocks, no rotation (mfma_path_ok / the entry points
       // have seen to that), 4- or 8-wave workgroups
       if (int rc = launch_decode_other_heads(la, head_size, waves >= 8 ? 8 : DEC_WAVES, dtype)) return rc;

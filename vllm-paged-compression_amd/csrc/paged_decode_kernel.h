@@ -589,5 +589,8 @@ static int decode_diag_fetch_tu(unsigned int* out, int reset) {
 // paged_decode_hs.hip: head sizes 32, 80, 96, 112, 120, 192 (16-token blocks, 4 or 8 waves)
 int launch_decode_other_heads(const DecLaunch& a, int head_size, int waves, int dtype);
 int decode_hs_diag_fetch(unsigned int* out, int reset);
+// paged_decode_blk.hip: head sizes 32, 96, 192, 256 at 8- and 32-token blocks (4 or 8 waves)
+int launch_decode_other_blocks(const DecLaunch& a, int head_size, int block_size, int waves, int dtype);
+int decode_blk_diag_fetch(unsigned int* out, int reset);
 
 }  // namespace pe
