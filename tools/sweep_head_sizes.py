@@ -12,8 +12,7 @@ import vllm_paged_compression_amd.ops as ops  # noqa: E402
 dev = torch.device("cuda:0")
 
 
-def decode_us(D, B=64, Hq=32, Hkv=8, kv=776, layers=4, iters=10):
-    bs = 16
+def decode_us(D, B=64, Hq=32, Hkv=8, kv=776, layers=4, iters=10, bs=16):
     nblk = (kv + bs - 1) // bs
     nb = B * nblk + 8
     caches = [(torch.empty(nb, Hkv, D // 8, bs, 8, dtype=torch.bfloat16, device=dev).uniform_(-0.09, 0.09),
@@ -88,6 +87,25 @@ def main():
             t2, _ = decode_us(D, iters=2) if kind == "decode" else prefill_us(D, iters=1)
             row.append(f"{t2:.0f}")
             os.environ.pop(var, None)
+            ops.reload_env()
+        print("| " + " | ".join(row) + " |", flush=True)
+    # decode at the other page sizes of the reference's study (scripts/diff_page_sizes.sh:16)
+    print()
+    print("| head size | decode at 8-token blocks: matrix core us (TB/s) | general us | "
+          "at 32-token blocks: matrix core us (TB/s) | general us |")
+    print("|---|---|---|---|---|")
+    for D in (32, 64, 96, 128, 192, 256):
+        row = [str(D)]
+        for bs in (8, 32):
+            os.environ.pop("PE_DECODE_FORCE_GENERIC", None)
+            ops.reload_env()
+            t, nbytes = decode_us(D, bs=bs)
+            row.append(f"{t:.1f} ({nbytes / t / 1e6:.2f})")
+            os.environ["PE_DECODE_FORCE_GENERIC"] = "1"
+            ops.reload_env()
+            t2, _ = decode_us(D, iters=2, bs=bs)
+            row.append(f"{t2:.0f}")
+            os.environ.pop("PE_DECODE_FORCE_GENERIC", None)
             ops.reload_env()
         print("| " + " | ".join(row) + " |", flush=True)
 
